@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory from the REFERENCE implementation.
+
+Run in the build container only (needs /root/reference; never on the GPU box):
+
+    python tests/golden/make_golden.py
+
+The reference is imported unmodified; modules it needs that are absent here and play no
+part in the arithmetic (pytorch_model_summary, seaborn, tensorboard) are replaced by empty
+stand-ins in ``sys.modules``.  Inputs and weights come from the NumPy recipes in
+``oracle/r2plus1d.py`` (``synth_state``/``synth_clip``/``synth_labels``) and are loaded into
+the reference modules with ``load_state_dict`` -- so a fixture stores only the recipe's seed,
+the reference's OUTPUTS, and sub-sampled gradients (data, no reference source).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("REFERENCE_ROOT", "/root/reference")
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+_stub("pytorch_model_summary", summary=lambda *a, **k: "")
+_stub("seaborn")
+
+
+class _NoWriter:
+    def __init__(self, *a, **k):
+        pass
+
+    def __getattr__(self, name):
+        return lambda *a, **k: None
+
+
+_stub("torch.utils.tensorboard", SummaryWriter=_NoWriter)
+
+sys.path.insert(0, REF)     # the reference's own `src` package
+sys.path.insert(1, ROOT)    # oracle/ (weight + input recipes only)
+
+from oracle import r2plus1d as orc          # noqa: E402
+from src.models.R2Plus1D import R2Plus1DClassifier   # noqa: E402  (reference)
+from src.loss import FocalLoss, LDAMLoss, CELoss      # noqa: E402  (reference)
+
+torch.set_num_threads(8)
+
+
+def subsample(t: torch.Tensor, n: int = 48) -> np.ndarray:
+    f = t.detach().reshape(-1)
+    stride = max(1, f.numel() // n)
+    return f[::stride][:n].numpy().copy()
+
+
+def load_ref_model(layer_sizes, T, S, alpha, seed):
+    model = R2Plus1DClassifier(input_size=(3, T, S, S), num_classes=2, layer_sizes=layer_sizes, alpha=alpha)
+    params, bufs = orc.synth_state(layer_sizes, seed, alpha)
+    sd = {}
+    sd.update(params)
+    sd.update(bufs)
+    missing, unexpected = model.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    return model
+
+
+def model_fixture(tag, layer_sizes, B, T, S, alpha, seed, gamma=2.0, weight=(1.0, 1.0)):
+    model = load_ref_model(layer_sizes, T, S, alpha, seed)
+    model.train()
+    x = orc.synth_clip(B, T, S, seed)
+    y = orc.synth_labels(B, seed)
+    loss_fn = FocalLoss(weight=torch.tensor(weight, dtype=torch.float32), gamma=gamma)
+    feats = {}
+    h = model.res2plus1d.conv1.register_forward_hook(lambda m, i, o: feats.__setitem__("stem", o.detach()))
+    h2 = model.res2plus1d.register_forward_hook(lambda m, i, o: feats.__setitem__("trunk", o.detach()))
+    logits = model(x)
+    h.remove(); h2.remove()
+    loss = loss_fn(logits, y)
+    loss.backward()
+    out = {
+        "layer_sizes": np.array(layer_sizes), "B": B, "T": T, "S": S, "alpha": alpha, "seed": seed,
+        "gamma": gamma, "weight": np.array(weight, dtype=np.float32),
+        "logits": logits.detach().numpy(), "loss": loss.detach().numpy(),
+        "trunk": feats["trunk"].numpy(),
+        "stem_sub": subsample(feats["stem"], 256),
+        "stem_mean": feats["stem"].mean().numpy(), "stem_std": feats["stem"].std().numpy(),
+    }
+    names = []
+    for k, p in model.named_parameters():
+        names.append(k)
+        out["gsub/" + k] = subsample(p.grad)
+        out["gnorm/" + k] = np.float32(p.grad.norm().item())
+    out["param_names"] = np.array(names)
+    sd = model.state_dict()
+    for k in ("res2plus1d.conv1.spatio_conv.bn.running_mean", "res2plus1d.conv1.spatio_conv.bn.running_var",
+              "res2plus1d.conv5.block1.conv2.temporal_conv.bn.running_var", "linear.1.running_mean",
+              "linear.1.running_var"):
+        out["buf/" + k] = sd[k].numpy().copy()
+    out["nbt"] = sd["linear.1.num_batches_tracked"].numpy()
+    np.savez_compressed(os.path.join(HERE, tag + ".npz"), **out)
+    print(tag, "logits", logits.detach().numpy().ravel(), "loss", float(loss))
+
+
+def loss_fixture():
+    rng = np.random.default_rng(11)
+    out = {}
+    for B in (1, 8, 33):
+        x = torch.from_numpy((rng.standard_normal((B, 2)) * 2.5).astype("float32"))
+        y = torch.from_numpy(rng.integers(0, 2, size=B).astype("int64"))
+        w = torch.tensor([1.7, 0.3])
+        out[f"x{B}"] = x.numpy(); out[f"y{B}"] = y.numpy(); out["w"] = w.numpy()
+        for name, fn in (
+            ("focal_g2", FocalLoss(weight=w, gamma=2.0)),
+            ("focal_g0p5", FocalLoss(weight=w, gamma=0.5)),
+            ("ldam_s30", LDAMLoss([100, 2000], max_m=0.5, weight=w, s=30)),
+            ("ldam_s1_now", LDAMLoss([100, 2000], max_m=0.5, weight=None, s=1)),
+            ("ce", CELoss(weight=w)),
+        ):
+            xx = x.clone().requires_grad_(True)
+            L = fn(xx, y)
+            L.backward()
+            out[f"{name}/L{B}"] = L.detach().numpy()
+            out[f"{name}/g{B}"] = xx.grad.numpy()
+    out["m_list"] = LDAMLoss([100, 2000], max_m=0.5).m_list.numpy()
+    # Gradient blending (reference: src/GradientBlending.py:45-50)
+    from src.GradientBlending import GradientBlending
+    B = 8
+    xs = [torch.from_numpy(rng.standard_normal((B, 2)).astype("float32")).requires_grad_(True) for _ in range(3)]
+    y = torch.from_numpy(rng.integers(0, 2, size=B).astype("int64"))
+    w = torch.tensor([1.0, 1.0])
+    gb = GradientBlending(FocalLoss(w, 2.0), FocalLoss(w, 2.0), FocalLoss(w, 2.0), 0.1, 0.4, 0.5)
+    L = gb(xs[0], xs[1], xs[2], y)
+    L.backward()
+    out["gb/y"] = y.numpy()
+    for i, n in enumerate(("multi", "vis", "ts")):
+        out[f"gb/x_{n}"] = xs[i].detach().numpy(); out[f"gb/g_{n}"] = xs[i].grad.numpy()
+    out["gb/L"] = L.detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "losses.npz"), **out)
+    print("losses ok")
+
+
+def drw_fixture():
+    # DRW schedule (reference: closure inside train_DRW, src/train.py:318-329) -- restated call-for-call
+    # by running the reference's train_DRW would need a dataset; the closure is pure NumPy, so the
+    # fixture records its outputs by executing the same statements through the reference function
+    # object extracted from the module source is not possible (it is a closure).  We therefore run
+    # train_DRW for real on a 1-batch synthetic loader with a recording loss function.
+    from src.train import train_DRW
+    torch.autograd.set_detect_anomaly(False)
+    rec = {}
+
+    class RecLoss(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.model_type = "Focal"
+            self.cur = None
+
+        def update_weight(self, w):
+            self.cur = w.detach().cpu().numpy().copy()
+            self.log.append(self.cur)
+
+        def forward(self, out, tgt):
+            return torch.nn.functional.cross_entropy(out, tgt, reduction="sum")
+
+    lin = torch.nn.Linear(4, 2)
+    data = [(torch.randn(4, 4), torch.tensor([0, 1, 1, 0]))]
+    for num_epoch in (8, 50, 128):
+        lf = RecLoss(); lf.log = []
+        opt = torch.optim.SGD(lin.parameters(), lr=0.0)
+        train_DRW(data, data, lin, opt, lf, "cpu", num_epoch, verbose=None,
+                  save_best_dir="/tmp/_g_best.pt", save_last_dir="/tmp/_g_last.pt", exp_dir="/tmp/_g_exp",
+                  max_norm_grad=1.0, betas=[0, 0.25, 0.75, 0.9], cls_num_list=[100, 2000])
+        rec[f"w{num_epoch}"] = np.stack(lf.log)
+    np.savez_compressed(os.path.join(HERE, "drw.npz"), **rec)
+    print("drw ok", {k: v.shape for k, v in rec.items()})
+
+
+def step_fixture():
+    """train_per_epoch (reference src/train.py:17-93) on 3 fixed batches of a tiny R2Plus1D."""
+    from src.train import train_per_epoch
+    torch.autograd.set_detect_anomaly(False)
+    layer_sizes, B, T, S, alpha, seed = [1, 1, 1, 1], 4, 4, 32, 0.01, 5
+    model = load_ref_model(layer_sizes, T, S, alpha, seed)
+    batches = [(orc.synth_clip(B, T, S, seed + i), orc.synth_labels(B, seed + i, 0.4)) for i in range(3)]
+    opt = torch.optim.AdamW(model.parameters(), lr=2e-4)
+    loss_fn = FocalLoss(weight=torch.tensor([1.0, 1.0]), gamma=2.0)
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    preds = []
+    hook = model.register_forward_hook(lambda m, i, o: preds.append(torch.softmax(o, 1).max(1)[1].numpy().copy()))
+    tl, ta, tf = train_per_epoch(batches, model, opt, None, loss_fn, "cpu", 1.0, "single")
+    hook.remove()
+    out = {"layer_sizes": np.array(layer_sizes), "B": B, "T": T, "S": S, "alpha": alpha, "seed": seed,
+           "train_loss": np.float64(tl), "train_acc": np.float64(ta), "train_f1": np.float64(tf),
+           "preds": np.stack(preds)}
+    for k, p in model.named_parameters():
+        out["dsub/" + k] = subsample(p.detach() - before[k])
+    np.savez_compressed(os.path.join(HERE, "step_tiny.npz"), **out)
+    print("step", tl, ta, tf, np.stack(preds))
+
+
+if __name__ == "__main__":
+    model_fixture("r2p1d_tiny_a001", [1, 1, 1, 1], B=2, T=5, S=32, alpha=0.01, seed=1)
+    model_fixture("r2p1d_1221_a1", [1, 2, 2, 1], B=3, T=6, S=48, alpha=1.0, seed=2, gamma=2.0, weight=(0.6, 1.4))
+    model_fixture("r2p1d_1221_odd", [1, 2, 2, 1], B=2, T=7, S=40, alpha=0.2, seed=3, gamma=1.5, weight=(1.0, 1.0))
+    loss_fixture()
+    drw_fixture()
+    step_fixture()

@@ -1,0 +1,417 @@
+// BatchNorm3d (train) + LeakyReLU + residual pieces that sit between two convolutions of the reference's
+// Conv3dBlock / SpatioTemporalResBlock (src/models/R2Plus1D.py:53-58, :179-187), for channels-last
+// fp32 tensors [rows][Cp].  All kernels are HBM-bound streaming passes: every thread owns one fixed
+// 16-byte channel chunk (so per-channel constants are loaded once) and walks rows; consecutive threads
+// touch consecutive 16-byte chunks, i.e. fully coalesced 1 KiB wave accesses.
+#include "common.h"
+
+struct View {
+  const float* p; const float* scale; const float* shift; float slope;
+};
+static inline View to_view(const MdActView* v) {
+  View o; o.p = v ? v->data : nullptr; o.scale = v ? v->scale : nullptr; o.shift = v ? v->shift : nullptr;
+  o.slope = v ? v->slope : 1.f; return o;
+}
+
+struct ChanConst { float4 sc, sh; };
+__device__ __forceinline__ ChanConst load_cc(const View& v, int c4) {
+  ChanConst k;
+  if (v.scale) { k.sc = *(const float4*)(v.scale + c4 * 4); k.sh = *(const float4*)(v.shift + c4 * 4); }
+  else { k.sc = make_float4(1.f, 1.f, 1.f, 1.f); k.sh = make_float4(0.f, 0.f, 0.f, 0.f); }
+  return k;
+}
+__device__ __forceinline__ float4 pre_of(const View& v, const ChanConst& k, float4 x) {
+  if (!v.scale) return x;
+  return make_float4(fmaf(x.x, k.sc.x, k.sh.x), fmaf(x.y, k.sc.y, k.sh.y), fmaf(x.z, k.sc.z, k.sh.z), fmaf(x.w, k.sc.w, k.sh.w));
+}
+__device__ __forceinline__ float4 act_of(const View& v, float4 pre) {
+  if (!v.scale) return pre;
+  return make_float4(md_leaky(pre.x, v.slope), md_leaky(pre.y, v.slope), md_leaky(pre.z, v.slope), md_leaky(pre.w, v.slope));
+}
+__device__ __forceinline__ float4 dact_of(const View& v, float4 pre) {
+  if (!v.scale) return make_float4(1.f, 1.f, 1.f, 1.f);
+  return make_float4(md_dleaky(pre.x, v.slope), md_dleaky(pre.y, v.slope), md_dleaky(pre.z, v.slope), md_dleaky(pre.w, v.slope));
+}
+__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// Row walk shared by the streaming kernels: thread -> (chunk c4, row lane r); block -> row range.
+struct RowWalk { int c4, r, nr; int64_t beg, end; bool active; };
+__device__ __forceinline__ RowWalk row_walk(int64_t rows, int C4) {
+  RowWalk w;
+  w.nr = blockDim.x / C4;
+  w.c4 = threadIdx.x % C4;
+  w.r = threadIdx.x / C4;
+  w.active = w.r < w.nr;
+  const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+  w.beg = (int64_t)blockIdx.x * per;
+  w.end = w.beg + per < rows ? w.beg + per : rows;
+  return w;
+}
+
+static int stream_blocks(int64_t rows, int C4) {
+  const int nr = 256 / C4;
+  int64_t b = md_cdiv64(rows, (int64_t)nr * 8);
+  if (b < 1) b = 1;
+  if (b > 4096) b = 4096;
+  return (int)b;
+}
+
+// ---------------------------------------------------------------- forward elementwise
+__global__ __launch_bounds__(256) void k_bn_act(View v, int64_t rows, int C4, float* __restrict__ out) {
+  RowWalk w = row_walk(rows, C4);
+  if (!w.active) return;
+  const ChanConst k = load_cc(v, w.c4);
+  for (int64_t row = w.beg + w.r; row < w.end; row += w.nr) {
+    const size_t o = ((size_t)row * C4 + w.c4) * 4;
+    *(float4*)(out + o) = act_of(v, pre_of(v, k, *(const float4*)(v.p + o)));
+  }
+}
+
+__global__ __launch_bounds__(256) void k_residual_fwd(View skip, View main, float alpha, int64_t rows, int C4,
+                                                      float* __restrict__ z) {
+  RowWalk w = row_walk(rows, C4);
+  if (!w.active) return;
+  const ChanConst ks = load_cc(skip, w.c4), km = load_cc(main, w.c4);
+  for (int64_t row = w.beg + w.r; row < w.end; row += w.nr) {
+    const size_t o = ((size_t)row * C4 + w.c4) * 4;
+    const float4 a = act_of(skip, pre_of(skip, ks, *(const float4*)(skip.p + o)));
+    const float4 b = act_of(main, pre_of(main, km, *(const float4*)(main.p + o)));
+    const float4 s = add4(a, b);
+    *(float4*)(z + o) = make_float4(md_leaky(s.x, alpha), md_leaky(s.y, alpha), md_leaky(s.z, alpha), md_leaky(s.w, alpha));
+  }
+}
+
+// ---------------------------------------------------------------- BatchNorm statistics finalize
+// grid = Cp/16 blocks; thread (c = t&15, r = t>>4) sums partial rows r, r+16, ... in fp64, then a fixed
+// tree over r: deterministic for a given launch geometry.
+__global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ partial, int blocks, int C, int Cp,
+                                                     double inv_count, double unbias, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps, float momentum,
+                                                     float* __restrict__ rmean, float* __restrict__ rvar,
+                                                     float* __restrict__ mean_o, float* __restrict__ invstd_o,
+                                                     float* __restrict__ scale_o, float* __restrict__ shift_o) {
+  __shared__ double s1[16][17], s2[16][17];
+  const int cl = threadIdx.x & 15, r = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  double a = 0.0, b = 0.0;
+  if (c < Cp) {
+    for (int i = r; i < blocks; i += 16) {
+      a += (double)partial[(size_t)i * 2 * Cp + c];
+      b += (double)partial[(size_t)i * 2 * Cp + Cp + c];
+    }
+  }
+  s1[r][cl] = a; s2[r][cl] = b;
+  __syncthreads();
+  for (int st = 8; st >= 1; st >>= 1) {
+    if (r < st) { s1[r][cl] += s1[r + st][cl]; s2[r][cl] += s2[r + st][cl]; }
+    __syncthreads();
+  }
+  if (r == 0 && c < Cp) {
+    float mean = 0.f, invstd = 0.f, sc = 0.f, sh = 0.f;
+    if (c < C) {
+      const double m = s1[0][cl] * inv_count;
+      double var = s2[0][cl] * inv_count - m * m;
+      if (var < 0.0) var = 0.0;
+      const double is = 1.0 / sqrt(var + (double)eps);
+      mean = (float)m; invstd = (float)is;
+      sc = gamma[c] * invstd;
+      sh = beta[c] - mean * sc;
+      if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+      if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(var * unbias);
+    }
+    mean_o[c] = mean; invstd_o[c] = invstd; scale_o[c] = sc; shift_o[c] = sh;
+  }
+}
+
+// eval mode: scale/shift from the running statistics (nn.BatchNorm3d.eval()).
+__global__ void k_bn_eval_params(int C, int Cp, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                 const float* __restrict__ rmean, const float* __restrict__ rvar, float eps,
+                                 float* __restrict__ mean_o, float* __restrict__ invstd_o, float* __restrict__ scale_o,
+                                 float* __restrict__ shift_o) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cp) return;
+  float mean = 0.f, is = 0.f, sc = 0.f, sh = 0.f;
+  if (c < C) { mean = rmean[c]; is = 1.f / sqrtf(rvar[c] + eps); sc = gamma[c] * is; sh = beta[c] - mean * sc; }
+  mean_o[c] = mean; invstd_o[c] = is; scale_o[c] = sc; shift_o[c] = sh;
+}
+
+// ---------------------------------------------------------------- BatchNorm backward
+// g = dA * leaky'_main(pre_main); closing form: dS = dZ * leaky'_alpha(act(skip) + act(main)), g = dS * leaky'(pre).
+template <bool APPLY>
+__global__ __launch_bounds__(256) void k_bn_bwd(const float* __restrict__ dA, View main, View skip, int has_skip,
+                                                float alpha, const float* __restrict__ mean,
+                                                const float* __restrict__ invstd, const float* __restrict__ coef,
+                                                int64_t rows, int C4, float* __restrict__ partial,
+                                                float* __restrict__ d_raw, float* __restrict__ dS) {
+  __shared__ float4 red[256];
+  RowWalk w = row_walk(rows, C4);
+  const int Cp = C4 * 4;
+  float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1;
+  if (w.active) {
+    const ChanConst km = load_cc(main, w.c4);
+    ChanConst ks; if (has_skip) ks = load_cc(skip, w.c4);
+    const float4 mu = *(const float4*)(mean + w.c4 * 4), is = *(const float4*)(invstd + w.c4 * 4);
+    float4 c1, c2;
+    if (APPLY) { c1 = *(const float4*)(coef + w.c4 * 4); c2 = *(const float4*)(coef + Cp + w.c4 * 4); }
+    for (int64_t row = w.beg + w.r; row < w.end; row += w.nr) {
+      const size_t o = ((size_t)row * C4 + w.c4) * 4;
+      const float4 raw = *(const float4*)(main.p + o);
+      const float4 pre = pre_of(main, km, raw);
+      float4 d = *(const float4*)(dA + o);
+      if (has_skip) {
+        const float4 sv = act_of(skip, pre_of(skip, ks, *(const float4*)(skip.p + o)));
+        const float4 sum = add4(sv, act_of(main, pre));
+        d = mul4(d, make_float4(md_dleaky(sum.x, alpha), md_dleaky(sum.y, alpha), md_dleaky(sum.z, alpha), md_dleaky(sum.w, alpha)));
+        if (APPLY) *(float4*)(dS + o) = d;
+      }
+      const float4 gq = mul4(d, dact_of(main, pre));
+      const float4 xh = make_float4((raw.x - mu.x) * is.x, (raw.y - mu.y) * is.y, (raw.z - mu.z) * is.z, (raw.w - mu.w) * is.w);
+      if (APPLY) {
+        float4 r;
+        r.x = km.sc.x * (gq.x - c1.x - xh.x * c2.x);
+        r.y = km.sc.y * (gq.y - c1.y - xh.y * c2.y);
+        r.z = km.sc.z * (gq.z - c1.z - xh.z * c2.z);
+        r.w = km.sc.w * (gq.w - c1.w - xh.w * c2.w);
+        *(float4*)(d_raw + o) = r;
+      } else {
+        a1 = add4(a1, gq);
+        a2 = add4(a2, mul4(gq, xh));
+      }
+    }
+  }
+  if (!APPLY) {
+    // reduce over the row lanes of this block (fixed order), one partial row per block
+    float* sp = partial + (size_t)blockIdx.x * 2 * Cp;
+    red[threadIdx.x] = a1;
+    __syncthreads();
+    if (w.r == 0 && w.active) {
+      float4 s = red[w.c4];
+      for (int r = 1; r < w.nr; ++r) s = add4(s, red[r * C4 + w.c4]);
+      *(float4*)(sp + w.c4 * 4) = s;
+    }
+    __syncthreads();
+    red[threadIdx.x] = a2;
+    __syncthreads();
+    if (w.r == 0 && w.active) {
+      float4 s = red[w.c4];
+      for (int r = 1; r < w.nr; ++r) s = add4(s, red[r * C4 + w.c4]);
+      *(float4*)(sp + Cp + w.c4 * 4) = s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict__ partial, int blocks, int C, int Cp,
+                                                         double inv_count, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbeta, float* __restrict__ coef) {
+  __shared__ double s1[16][17], s2[16][17];
+  const int cl = threadIdx.x & 15, r = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  double a = 0.0, b = 0.0;
+  if (c < Cp) {
+    for (int i = r; i < blocks; i += 16) {
+      a += (double)partial[(size_t)i * 2 * Cp + c];
+      b += (double)partial[(size_t)i * 2 * Cp + Cp + c];
+    }
+  }
+  s1[r][cl] = a; s2[r][cl] = b;
+  __syncthreads();
+  for (int st = 8; st >= 1; st >>= 1) {
+    if (r < st) { s1[r][cl] += s1[r + st][cl]; s2[r][cl] += s2[r + st][cl]; }
+    __syncthreads();
+  }
+  if (r == 0 && c < Cp) {
+    const double g1 = s1[0][cl], g2 = s2[0][cl];
+    if (c < C) { if (dbeta) dbeta[c] = (float)g1; if (dgamma) dgamma[c] = (float)g2; }
+    coef[c] = (float)(g1 * inv_count);
+    coef[Cp + c] = (float)(g2 * inv_count);
+  }
+}
+
+// ---------------------------------------------------------------- layout conversion, pooling
+__global__ __launch_bounds__(256) void k_nchw_to_cl(const float* __restrict__ x, int C, int C4, int64_t thw, int64_t total,
+                                                    float* __restrict__ out) {
+  // one thread per (pixel, 16-byte chunk); reads are coalesced along the pixel axis of each plane
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int64_t pix = idx / C4; const int c4 = (int)(idx - pix * C4);
+  const int64_t b = pix / thw, p = pix - b * thw;
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { const int c = c4 * 4 + e; v[e] = c < C ? x[((size_t)b * C + c) * thw + p] : 0.f; }
+  *(float4*)(out + (size_t)idx * 4) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__global__ __launch_bounds__(256) void k_cl_to_nchw(const float* __restrict__ x, int C, int Cp, int64_t thw, int64_t total,
+                                                    float* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over [B][C][thw]
+  if (idx >= total) return;
+  const int64_t p = idx % thw; const int64_t bc = idx / thw; const int c = (int)(bc % C); const int64_t b = bc / C;
+  out[idx] = x[((size_t)b * thw + p) * Cp + c];
+}
+
+__global__ __launch_bounds__(256) void k_avgpool_fwd(const float* __restrict__ x, int C, int C4, int64_t thw, float* __restrict__ feat) {
+  __shared__ float4 red[256];
+  const int nr = blockDim.x / C4, c4 = threadIdx.x % C4, r = threadIdx.x / C4;
+  const float* xb = x + (size_t)blockIdx.x * thw * C4 * 4;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (r < nr) for (int64_t row = r; row < thw; row += nr) a = add4(a, *(const float4*)(xb + ((size_t)row * C4 + c4) * 4));
+  red[threadIdx.x] = a;
+  __syncthreads();
+  if (r == 0) {
+    float4 s = red[c4];
+    for (int q = 1; q < nr; ++q) s = add4(s, red[q * C4 + c4]);
+    const float inv = 1.f / (float)thw;
+    const float v[4] = {s.x * inv, s.y * inv, s.z * inv, s.w * inv};
+    for (int e = 0; e < 4; ++e) if (c4 * 4 + e < C) feat[(size_t)blockIdx.x * C + c4 * 4 + e] = v[e];
+  }
+}
+__global__ __launch_bounds__(256) void k_avgpool_bwd(const float* __restrict__ dfeat, int C, int C4, int64_t thw, int64_t total,
+                                                     float* __restrict__ dx) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over [B][thw][C4]
+  if (idx >= total) return;
+  const int c4 = (int)(idx % C4); const int64_t b = idx / C4 / thw;
+  const float inv = 1.f / (float)thw;
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { const int c = c4 * 4 + e; v[e] = c < C ? dfeat[(size_t)b * C + c] * inv : 0.f; }
+  *(float4*)(dx + (size_t)idx * 4) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// ---------------------------------------------------------------- host side
+extern "C" int md_bn_finalize(const float* stat_partial, int32_t blocks, int32_t C, int64_t count, const float* gamma,
+                              const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                              float* mean, float* invstd, float* scale, float* shift, void* stream) {
+  if (!stat_partial || !gamma || !beta || !mean || !invstd || !scale || !shift) return MD_ERR_NULL;
+  if (C <= 0 || blocks <= 0 || count <= 0) return MD_ERR_BAD_SHAPE;
+  const int Cp = md_cpad(C);
+  const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
+  hipLaunchKernelGGL(k_bn_finalize, dim3(md_cdiv(Cp, 16)), dim3(256), 0, (hipStream_t)stream, stat_partial, blocks, C, Cp,
+                     1.0 / (double)count, unbias, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
+                     scale, shift);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+extern "C" int md_bn_eval_params(int32_t C, const float* gamma, const float* beta, const float* rmean, const float* rvar,
+                                 float eps, float* mean, float* invstd, float* scale, float* shift, void* stream) {
+  if (!gamma || !beta || !rmean || !rvar || !mean || !invstd || !scale || !shift) return MD_ERR_NULL;
+  if (C <= 0) return MD_ERR_BAD_SHAPE;
+  const int Cp = md_cpad(C);
+  hipLaunchKernelGGL(k_bn_eval_params, dim3(md_cdiv(Cp, 256)), dim3(256), 0, (hipStream_t)stream, C, Cp, gamma, beta, rmean,
+                     rvar, eps, mean, invstd, scale, shift);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+static int check_rows(int64_t rows, int32_t C) {
+  if (rows <= 0 || C <= 0) return MD_ERR_BAD_SHAPE;
+  if (md_cpad(C) / 4 > 256) return MD_ERR_UNSUPPORTED;
+  return MD_OK;
+}
+
+extern "C" int md_bn_act(const MdActView* x, int64_t rows, int32_t C, float* out, void* stream) {
+  if (!x || !x->data || !out) return MD_ERR_NULL;
+  int rc = check_rows(rows, C); if (rc) return rc;
+  const int C4 = md_cpad(C) / 4;
+  hipLaunchKernelGGL(k_bn_act, dim3(stream_blocks(rows, C4)), dim3(256), 0, (hipStream_t)stream, to_view(x), rows, C4, out);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+extern "C" int md_residual_fwd(const MdActView* skip, const MdActView* main, float alpha, int64_t rows, int32_t C,
+                               float* z, void* stream) {
+  if (!skip || !main || !skip->data || !main->data || !z) return MD_ERR_NULL;
+  int rc = check_rows(rows, C); if (rc) return rc;
+  const int C4 = md_cpad(C) / 4;
+  hipLaunchKernelGGL(k_residual_fwd, dim3(stream_blocks(rows, C4)), dim3(256), 0, (hipStream_t)stream, to_view(skip),
+                     to_view(main), alpha, rows, C4, z);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+extern "C" int32_t md_bn_bwd_blocks(int64_t rows, int32_t C) {
+  if (check_rows(rows, C) != MD_OK) return 0;
+  const int C4 = md_cpad(C) / 4;
+  const int nr = 256 / C4;
+  int64_t b = md_cdiv64(rows, (int64_t)nr * 16);
+  if (b < 1) b = 1;
+  if (b > 2048) b = 2048;
+  return (int32_t)b;
+}
+
+extern "C" int md_bn_bwd_reduce(const float* dA, const MdActView* main, const MdActView* skip, float alpha,
+                                const float* mean, const float* invstd, int64_t rows, int32_t C, float* partial,
+                                void* stream) {
+  if (!dA || !main || !main->data || !mean || !invstd || !partial) return MD_ERR_NULL;
+  int rc = check_rows(rows, C); if (rc) return rc;
+  const int C4 = md_cpad(C) / 4;
+  hipLaunchKernelGGL(k_bn_bwd<false>, dim3(md_bn_bwd_blocks(rows, C)), dim3(256), 0, (hipStream_t)stream, dA,
+                     to_view(main), to_view(skip), skip != nullptr ? 1 : 0, alpha, mean, invstd, (const float*)nullptr,
+                     rows, C4, partial, (float*)nullptr, (float*)nullptr);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+extern "C" int md_bn_bwd_finalize(const float* partial, int32_t blocks, int32_t C, int64_t count, float* dgamma,
+                                  float* dbeta, float* coef, void* stream) {
+  if (!partial || !coef) return MD_ERR_NULL;
+  if (C <= 0 || blocks <= 0 || count <= 0) return MD_ERR_BAD_SHAPE;
+  const int Cp = md_cpad(C);
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(md_cdiv(Cp, 16)), dim3(256), 0, (hipStream_t)stream, partial, blocks, C, Cp,
+                     1.0 / (double)count, dgamma, dbeta, coef);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+extern "C" int md_bn_bwd_apply(const float* dA, const MdActView* main, const MdActView* skip, float alpha,
+                               const float* mean, const float* invstd, const float* coef, int64_t rows, int32_t C,
+                               float* d_raw, float* dS, void* stream) {
+  if (!dA || !main || !main->data || !mean || !invstd || !coef || !d_raw) return MD_ERR_NULL;
+  if (skip != nullptr && !dS) return MD_ERR_NULL;
+  int rc = check_rows(rows, C); if (rc) return rc;
+  const int C4 = md_cpad(C) / 4;
+  hipLaunchKernelGGL(k_bn_bwd<true>, dim3(stream_blocks(rows, C4)), dim3(256), 0, (hipStream_t)stream, dA, to_view(main),
+                     to_view(skip), skip != nullptr ? 1 : 0, alpha, mean, invstd, coef, rows, C4, (float*)nullptr,
+                     d_raw, dS);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+extern "C" int md_nchw_to_cl(const float* x, int32_t B, int32_t C, int64_t thw, float* out, void* stream) {
+  if (!x || !out) return MD_ERR_NULL;
+  if (B <= 0 || C <= 0 || thw <= 0) return MD_ERR_BAD_SHAPE;
+  const int C4 = md_cpad(C) / 4;
+  const int64_t total = (int64_t)B * thw * C4;
+  hipLaunchKernelGGL(k_nchw_to_cl, dim3((unsigned)md_cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, x, C, C4, thw,
+                     total, out);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+extern "C" int md_cl_to_nchw(const float* x, int32_t B, int32_t C, int64_t thw, float* out, void* stream) {
+  if (!x || !out) return MD_ERR_NULL;
+  if (B <= 0 || C <= 0 || thw <= 0) return MD_ERR_BAD_SHAPE;
+  const int64_t total = (int64_t)B * C * thw;
+  hipLaunchKernelGGL(k_cl_to_nchw, dim3((unsigned)md_cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, x, C, md_cpad(C),
+                     thw, total, out);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+extern "C" int md_avgpool_fwd(const float* x, int32_t B, int32_t C, int64_t thw, float* feat, void* stream) {
+  if (!x || !feat) return MD_ERR_NULL;
+  int rc = check_rows(thw, C); if (rc) return rc;
+  if (B <= 0) return MD_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(k_avgpool_fwd, dim3(B), dim3(256), 0, (hipStream_t)stream, x, C, md_cpad(C) / 4, thw, feat);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+extern "C" int md_avgpool_bwd(const float* dfeat, int32_t B, int32_t C, int64_t thw, float* dx, void* stream) {
+  if (!dfeat || !dx) return MD_ERR_NULL;
+  if (B <= 0 || C <= 0 || thw <= 0) return MD_ERR_BAD_SHAPE;
+  const int C4 = md_cpad(C) / 4;
+  const int64_t total = (int64_t)B * thw * C4;
+  hipLaunchKernelGGL(k_avgpool_bwd, dim3((unsigned)md_cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, dfeat, C, C4, thw,
+                     total, dx);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}

@@ -1,0 +1,42 @@
+// Shared declarations for the gfx950 kernels of the disruption-predictor hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mi355x_disrupt.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MD_ABI_VERSION 1
+
+static inline int md_cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t md_cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int md_round_up(int a, int b) { return md_cdiv(a, b) * b; }
+
+#define MD_CHECK_LAUNCH()                                  \
+  do {                                                     \
+    hipError_t e__ = hipGetLastError();                    \
+    if (e__ != hipSuccess) return MD_ERR_LAUNCH;           \
+  } while (0)
+
+// Geometry of one implicit GEMM: rows = destination pixels, K = taps x source channels.
+// A source coordinate along dimension d is  (o*sn + off + sign*tap) / sd  and is valid only
+// when the division is exact and the result lies inside the source tensor.  Forward conv:
+// sn = stride, sd = 1, off = -pad, sign = +1.  Data gradient: sn = 1, sd = stride, off = +pad,
+// sign = -1 (a gather formulation of the transposed conv, so no scatter / atomics are needed).
+struct Geom {
+  int Ti, Hi, Wi, Cpi;   // source tensor [N][Ti][Hi][Wi][Cpi]
+  int To, Ho, Wo, Cpo;   // destination tensor [N][To][Ho][Wo][Cpo]
+  int kh, kw, khw;
+  int sn_t, sn_h, sn_w;
+  int sd_t, sd_h, sd_w;
+  int off_t, off_h, off_w;
+  int sign;
+  int M;        // destination rows
+  int Kc;       // K / 4 (16-byte chunks of the flat K axis)
+  int Kp;       // row pitch of the packed weights (floats, multiple of 32)
+  int nstages;  // Kp / 32
+  int N16;      // packed weight rows (destination channels rounded up to 16)
+};
+
+__device__ __forceinline__ float md_leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
+__device__ __forceinline__ float md_dleaky(float pre, float slope) { return pre > 0.f ? 1.f : slope; }

@@ -1,0 +1,293 @@
+// Whole-trunk executor for R2Plus1DNet (src/models/R2Plus1D.py:207-226): builds the unit / block list of
+// the network once (host metadata only) and replays forward and backward as a fixed sequence of launches on
+// the caller's stream -- no allocation, no synchronisation, so the sequence can be captured in a hipGraph.
+//
+// Fusion plan (what is materialised in HBM):
+//   * every Conv3dBlock writes only its RAW conv output (+ per-block partial BN sums from the epilogue);
+//     BatchNorm + LeakyReLU are applied by the CONSUMER while it stages its input ("BN-on-read");
+//   * block outputs z = leaky(skip + main) are materialised (two consumers each);
+//   * backward keeps 4 gradient scratch buffers and runs BN-backward in place.
+#include <vector>
+#include <new>
+#include "common.h"
+
+extern "C" int md_bn_eval_params(int32_t C, const float* gamma, const float* beta, const float* rmean, const float* rvar,
+                                 float eps, float* mean, float* invstd, float* scale, float* shift, void* stream);
+
+struct Unit {
+  MdConvDesc d;
+  int in_unit;      // >=0: input is the raw output of that unit, BN+act applied on read
+  int in_z;         // >=0: input is materialised tensor z[in_z]
+  float slope;
+  int stage;
+  int64_t rows;     // output pixels
+  size_t raw_off, stat_off, wf_off, wd_off;   // float offsets into the workspace
+  int Cp;
+};
+struct Block {
+  int c1s, c1t, c2s, c2t, dss, dst;   // unit ids (dss/dst = -1 without downsample)
+  int in_z, out_z, stage;
+};
+struct ZT { int C; int64_t rows; size_t off; };
+
+struct MdPlan {
+  int B, T, H, W;
+  float alpha;
+  std::vector<Unit> units;
+  std::vector<Block> blocks;
+  std::vector<ZT> z;
+  size_t part_off, coef_off, g_off[4], gmax, total_floats;
+  size_t part_floats;
+  int feat_dim;
+  int bwd_p;   // gradient buffer currently holding dZ
+};
+
+static int conv_out(int i, int k, int s, int p) { return (i + 2 * p - k) / s + 1; }
+
+static int add_unit(MdPlan* P, int Ti, int Hi, int Wi, int cin, int cout, int kt, int kh, int kw, int st, int sh, int sw,
+                    int pt, int ph, int pw, float slope, int in_unit, int in_z, int stage) {
+  Unit u;
+  u.d.N = P->B; u.d.Ti = Ti; u.d.Hi = Hi; u.d.Wi = Wi; u.d.Cin = cin; u.d.Cout = cout;
+  u.d.kt = kt; u.d.kh = kh; u.d.kw = kw; u.d.st = st; u.d.sh = sh; u.d.sw = sw; u.d.pt = pt; u.d.ph = ph; u.d.pw = pw;
+  u.d.To = conv_out(Ti, kt, st, pt); u.d.Ho = conv_out(Hi, kh, sh, ph); u.d.Wo = conv_out(Wi, kw, sw, pw);
+  u.in_unit = in_unit; u.in_z = in_z; u.slope = slope; u.stage = stage;
+  u.rows = (int64_t)P->B * u.d.To * u.d.Ho * u.d.Wo;
+  u.Cp = md_cpad(cout);
+  P->units.push_back(u);
+  return (int)P->units.size() - 1;
+}
+
+// SpatioTemporalConv (R2Plus1D.py:138-157): spatial (1,k,k) unit then temporal (k,1,1) unit.
+static void add_st_conv(MdPlan* P, int Ti, int Hi, int Wi, int cin, int cout, int k, int stride, int pad, int in_z, int stage,
+                        int* us, int* ut) {
+  const int mid = (int)((long long)k * k * k * cin * cout / ((long long)k * k * cin + (long long)k * cout));
+  *us = add_unit(P, Ti, Hi, Wi, cin, mid, 1, k, k, 1, stride, stride, 0, pad, pad, 0.01f, -1, in_z, stage);
+  const Unit& s = P->units[*us];
+  *ut = add_unit(P, s.d.To, s.d.Ho, s.d.Wo, mid, cout, k, 1, 1, stride, 1, 1, pad, 0, 0, 0.01f, *us, -1, stage);
+}
+
+extern "C" int md_plan_create(int32_t B, int32_t T, int32_t H, int32_t W, const int32_t* layer_sizes, float alpha,
+                              MdPlan** out) {
+  if (!layer_sizes || !out) return MD_ERR_NULL;
+  if (B <= 0 || T <= 0 || H <= 0 || W <= 0) return MD_ERR_BAD_SHAPE;
+  for (int i = 0; i < 4; ++i) if (layer_sizes[i] < 1) return MD_ERR_BAD_SHAPE;
+  MdPlan* P = new (std::nothrow) MdPlan();
+  if (!P) return MD_ERR_WORKSPACE;
+  P->B = B; P->T = T; P->H = H; P->W = W; P->alpha = alpha; P->bwd_p = 0;
+  // z[0] = input clip in channels-last
+  P->z.push_back(ZT{3, (int64_t)B * T * H * W, 0});
+  // stem (R2Plus1D.py:125-137,210): 7x7/s2 spatial with 45 mid channels, then k3 temporal
+  int us = add_unit(P, T, H, W, 3, 45, 1, 7, 7, 1, 2, 2, 0, 3, 3, alpha, -1, 0, 0);
+  const Unit s0 = P->units[us];
+  int ut = add_unit(P, s0.d.To, s0.d.Ho, s0.d.Wo, 45, 32, 3, 1, 1, 1, 1, 1, 1, 0, 0, alpha, us, -1, 0);
+  const Unit s1 = P->units[ut];
+  P->z.push_back(ZT{32, s1.rows, 0});
+  int cur_z = 1, curT = s1.d.To, curH = s1.d.Ho, curW = s1.d.Wo, curC = 32;
+  const int couts[4] = {32, 64, 64, 128};
+  for (int st = 0; st < 4; ++st) {
+    for (int bi = 0; bi < layer_sizes[st]; ++bi) {
+      const bool down = (bi == 0 && st > 0);
+      const int cout = couts[st];
+      Block b; b.stage = st + 1; b.in_z = cur_z; b.dss = b.dst = -1;
+      add_st_conv(P, curT, curH, curW, curC, cout, 3, down ? 2 : 1, 1, cur_z, st + 1, &b.c1s, &b.c1t);
+      const Unit t1 = P->units[b.c1t];
+      // conv2 takes the (not materialised) output of conv1.temporal
+      const int mid2 = (int)((long long)27 * cout * cout / ((long long)9 * cout + 3LL * cout));
+      b.c2s = add_unit(P, t1.d.To, t1.d.Ho, t1.d.Wo, cout, mid2, 1, 3, 3, 1, 1, 1, 0, 1, 1, 0.01f, b.c1t, -1, st + 1);
+      b.c2t = add_unit(P, t1.d.To, t1.d.Ho, t1.d.Wo, mid2, cout, 3, 1, 1, 1, 1, 1, 1, 0, 0, 0.01f, b.c2s, -1, st + 1);
+      if (down) add_st_conv(P, curT, curH, curW, curC, cout, 1, 2, 0, cur_z, st + 1, &b.dss, &b.dst);
+      const Unit t2 = P->units[b.c2t];
+      if (down) {
+        const Unit dt = P->units[b.dst];
+        if (dt.d.To != t2.d.To || dt.d.Ho != t2.d.Ho || dt.d.Wo != t2.d.Wo) { delete P; return MD_ERR_BAD_SHAPE; }
+      }
+      P->z.push_back(ZT{cout, t2.rows, 0});
+      b.out_z = (int)P->z.size() - 1;
+      P->blocks.push_back(b);
+      cur_z = b.out_z; curT = t2.d.To; curH = t2.d.Ho; curW = t2.d.Wo; curC = cout;
+    }
+  }
+  P->feat_dim = curC;
+  // workspace layout (floats, every region 64-float aligned)
+  size_t off = 0, gmax = 0, pmax = 0;
+  auto take = [&](size_t n) { size_t o = off; off += (n + 63) & ~(size_t)63; return o; };
+  for (auto& z : P->z) { const size_t n = (size_t)z.rows * md_cpad(z.C); z.off = take(n); if (n > gmax) gmax = n; }
+  for (auto& u : P->units) {
+    const size_t n = (size_t)u.rows * u.Cp;
+    u.raw_off = take(n); if (n > gmax) gmax = n;
+    u.stat_off = take((size_t)4 * u.Cp);
+    u.wf_off = take(md_conv_wpack_fwd_floats(&u.d));
+    u.wd_off = take(md_conv_wpack_dgrad_floats(&u.d));
+    size_t pf = (size_t)md_conv_fwd_stat_blocks(&u.d) * 2 * u.Cp;
+    const size_t pb = (size_t)md_bn_bwd_blocks(u.rows, u.d.Cout) * 2 * u.Cp;
+    if (pb > pf) pf = pb;
+    if (pf > pmax) pmax = pf;
+  }
+  P->part_floats = pmax;
+  P->part_off = take(pmax);
+  P->coef_off = take(2 * 1024);
+  P->gmax = gmax;
+  for (int i = 0; i < 4; ++i) P->g_off[i] = take(gmax);
+  P->total_floats = off;
+  *out = P;
+  return MD_OK;
+}
+
+extern "C" void md_plan_destroy(MdPlan* p) { delete p; }
+extern "C" int32_t md_plan_num_units(const MdPlan* p) { return p ? (int32_t)p->units.size() : 0; }
+extern "C" int md_plan_unit_desc(const MdPlan* p, int32_t i, MdConvDesc* out) {
+  if (!p || !out) return MD_ERR_NULL;
+  if (i < 0 || i >= (int)p->units.size()) return MD_ERR_BAD_SHAPE;
+  *out = p->units[i].d;
+  return MD_OK;
+}
+extern "C" size_t md_plan_workspace_bytes(const MdPlan* p) { return p ? p->total_floats * 4 : 0; }
+extern "C" int32_t md_plan_feat_dim(const MdPlan* p) { return p ? p->feat_dim : 0; }
+
+#define RC(x) do { int rc__ = (x); if (rc__ != MD_OK) return rc__; } while (0)
+
+static MdActView unit_out_view(const MdPlan* P, float* ws, int ui) {
+  const Unit& u = P->units[ui];
+  MdActView v; v.data = ws + u.raw_off; v.scale = ws + u.stat_off + 2 * u.Cp; v.shift = ws + u.stat_off + 3 * u.Cp;
+  v.slope = u.slope; return v;
+}
+static MdActView z_view(const MdPlan* P, float* ws, int zi) {
+  MdActView v; v.data = ws + P->z[zi].off; v.scale = nullptr; v.shift = nullptr; v.slope = 1.f; return v;
+}
+static MdActView unit_in_view(const MdPlan* P, float* ws, int ui) {
+  const Unit& u = P->units[ui];
+  return u.in_unit >= 0 ? unit_out_view(P, ws, u.in_unit) : z_view(P, ws, u.in_z);
+}
+
+extern "C" int md_plan_forward(MdPlan* P, const float* x, const float* const* w, const float* const* gamma,
+                               const float* const* beta, float* const* rmean, float* const* rvar, int training,
+                               float* feat, void* workspace, void* stream) {
+  if (!P || !x || !w || !gamma || !beta || !feat || !workspace) return MD_ERR_NULL;
+  if (!training && (!rmean || !rvar)) return MD_ERR_NULL;
+  float* ws = (float*)workspace;
+  RC(md_nchw_to_cl(x, P->B, 3, (int64_t)P->T * P->H * P->W, ws + P->z[0].off, stream));
+  size_t next_block = 0;
+  for (size_t i = 0; i < P->units.size(); ++i) {
+    const Unit& u = P->units[i];
+    RC(md_conv_pack_weights(&u.d, w[i], ws + u.wf_off, training ? ws + u.wd_off : nullptr, stream));
+    MdActView in = unit_in_view(P, ws, (int)i);
+    float* st = ws + u.stat_off;
+    if (training) {
+      RC(md_conv_fwd(&u.d, &in, ws + u.wf_off, ws + u.raw_off, ws + P->part_off, stream));
+      RC(md_bn_finalize(ws + P->part_off, md_conv_fwd_stat_blocks(&u.d), u.d.Cout, u.rows, gamma[i], beta[i], 1e-5f, 0.1f,
+                        rmean ? rmean[i] : nullptr, rvar ? rvar[i] : nullptr, st, st + u.Cp, st + 2 * u.Cp, st + 3 * u.Cp,
+                        stream));
+    } else {
+      RC(md_conv_fwd(&u.d, &in, ws + u.wf_off, ws + u.raw_off, nullptr, stream));
+      RC(md_bn_eval_params(u.d.Cout, gamma[i], beta[i], rmean[i], rvar[i], 1e-5f, st, st + u.Cp, st + 2 * u.Cp, st + 3 * u.Cp,
+                           stream));
+    }
+    if (i == 1) {   // stem output feeds a conv AND an identity skip: materialise it
+      MdActView v = unit_out_view(P, ws, 1);
+      RC(md_bn_act(&v, u.rows, u.d.Cout, ws + P->z[1].off, stream));
+    }
+    // close the residual block whose last unit this is
+    if (next_block < P->blocks.size()) {
+      const Block& b = P->blocks[next_block];
+      const int last = b.dst >= 0 ? b.dst : b.c2t;
+      if ((int)i == last) {
+        MdActView mainv = unit_out_view(P, ws, b.c2t);
+        MdActView skipv = b.dst >= 0 ? unit_out_view(P, ws, b.dst) : z_view(P, ws, b.in_z);
+        const Unit& t2 = P->units[b.c2t];
+        RC(md_residual_fwd(&skipv, &mainv, P->alpha, t2.rows, t2.d.Cout, ws + P->z[b.out_z].off, stream));
+        ++next_block;
+      }
+    }
+  }
+  const ZT& zl = P->z.back();
+  RC(md_avgpool_fwd(ws + zl.off, P->B, zl.C, zl.rows / P->B, feat, stream));
+  return MD_OK;
+}
+
+// BN-backward of unit ui given dA in G[gb] (overwritten with d_raw), then wgrad and (optionally) dgrad.
+static int unit_backward(MdPlan* P, float* ws, int ui, int gb, int dxb, int accumulate, bool bn_done,
+                         const float* const* w, float* const* dw, float* const* dgamma, float* const* dbeta, void* stream) {
+  const Unit& u = P->units[ui];
+  float* G = ws + P->g_off[gb];
+  float* st = ws + u.stat_off;
+  (void)w;
+  if (!bn_done) {
+    MdActView mainv = unit_out_view(P, ws, ui);
+    const int nb = md_bn_bwd_blocks(u.rows, u.d.Cout);
+    RC(md_bn_bwd_reduce(G, &mainv, nullptr, 1.f, st, st + u.Cp, u.rows, u.d.Cout, ws + P->part_off, stream));
+    RC(md_bn_bwd_finalize(ws + P->part_off, nb, u.d.Cout, u.rows, dgamma[ui], dbeta[ui], ws + P->coef_off, stream));
+    RC(md_bn_bwd_apply(G, &mainv, nullptr, 1.f, st, st + u.Cp, ws + P->coef_off, u.rows, u.d.Cout, G, nullptr, stream));
+  }
+  const size_t wn = (size_t)u.d.Cout * u.d.Cin * u.d.kt * u.d.kh * u.d.kw;
+  if (hipMemsetAsync(dw[ui], 0, wn * 4, (hipStream_t)stream) != hipSuccess) return MD_ERR_LAUNCH;
+  MdActView in = unit_in_view(P, ws, ui);
+  RC(md_conv_wgrad(&u.d, &in, G, dw[ui], stream));
+  if (dxb >= 0) RC(md_conv_dgrad(&u.d, G, ws + u.wd_off, ws + P->g_off[dxb], accumulate, stream));
+  return MD_OK;
+}
+
+static int block_backward(MdPlan* P, float* ws, const Block& b, const float* const* w, float* const* dw,
+                          float* const* dgamma, float* const* dbeta, void* stream) {
+  const int p = P->bwd_p;
+  int fr[3], n = 0;
+  for (int i = 0; i < 4; ++i) if (i != p) fr[n++] = i;
+  const int a = fr[0], bb = fr[1], c = fr[2];
+  const Unit& t2 = P->units[b.c2t];
+  float* st = ws + t2.stat_off;
+  MdActView mainv = unit_out_view(P, ws, b.c2t);
+  MdActView skipv = b.dst >= 0 ? unit_out_view(P, ws, b.dst) : z_view(P, ws, b.in_z);
+  const int nb = md_bn_bwd_blocks(t2.rows, t2.d.Cout);
+  float* Gp = ws + P->g_off[p];
+  RC(md_bn_bwd_reduce(Gp, &mainv, &skipv, P->alpha, st, st + t2.Cp, t2.rows, t2.d.Cout, ws + P->part_off, stream));
+  RC(md_bn_bwd_finalize(ws + P->part_off, nb, t2.d.Cout, t2.rows, dgamma[b.c2t], dbeta[b.c2t], ws + P->coef_off, stream));
+  RC(md_bn_bwd_apply(Gp, &mainv, &skipv, P->alpha, st, st + t2.Cp, ws + P->coef_off, t2.rows, t2.d.Cout,
+                     ws + P->g_off[a], Gp, stream));
+  RC(unit_backward(P, ws, b.c2t, a, bb, 0, true, w, dw, dgamma, dbeta, stream));
+  RC(unit_backward(P, ws, b.c2s, bb, a, 0, false, w, dw, dgamma, dbeta, stream));
+  RC(unit_backward(P, ws, b.c1t, a, bb, 0, false, w, dw, dgamma, dbeta, stream));
+  if (b.dst < 0) {
+    RC(unit_backward(P, ws, b.c1s, bb, p, 1, false, w, dw, dgamma, dbeta, stream));   // dX accumulates onto dS
+  } else {
+    RC(unit_backward(P, ws, b.c1s, bb, c, 0, false, w, dw, dgamma, dbeta, stream));
+    RC(unit_backward(P, ws, b.dst, p, a, 0, false, w, dw, dgamma, dbeta, stream));    // dS is dA of the skip path
+    RC(unit_backward(P, ws, b.dss, a, c, 1, false, w, dw, dgamma, dbeta, stream));
+    P->bwd_p = c;
+  }
+  return MD_OK;
+}
+
+extern "C" int md_plan_backward_range(MdPlan* P, const float* dfeat, const float* const* w, const float* const* gamma,
+                                      float* const* dw, float* const* dgamma, float* const* dbeta, void* workspace,
+                                      int32_t stage_hi, int32_t stage_lo, void* stream) {
+  if (!P || !w || !dw || !dgamma || !dbeta || !workspace) return MD_ERR_NULL;
+  (void)gamma;
+  if (stage_hi > 4 || stage_lo < 0 || stage_lo > stage_hi) return MD_ERR_BAD_SHAPE;
+  float* ws = (float*)workspace;
+  if (stage_hi == 4) {
+    if (!dfeat) return MD_ERR_NULL;
+    P->bwd_p = 0;
+    const ZT& zl = P->z.back();
+    RC(md_avgpool_bwd(dfeat, P->B, zl.C, zl.rows / P->B, ws + P->g_off[0], stream));
+  }
+  for (int bi = (int)P->blocks.size() - 1; bi >= 0; --bi) {
+    const Block& b = P->blocks[bi];
+    if (b.stage > stage_hi || b.stage < stage_lo) continue;
+    RC(block_backward(P, ws, b, w, dw, dgamma, dbeta, stream));
+  }
+  if (stage_lo == 0) {
+    const int p = P->bwd_p, q = (p + 1) & 3;
+    RC(unit_backward(P, ws, 1, p, q, 0, false, w, dw, dgamma, dbeta, stream));
+    RC(unit_backward(P, ws, 0, q, -1, 0, false, w, dw, dgamma, dbeta, stream));
+  }
+  return MD_OK;
+}
+
+extern "C" int md_plan_backward(MdPlan* P, const float* dfeat, const float* const* w, const float* const* gamma,
+                                float* const* dw, float* const* dgamma, float* const* dbeta, void* workspace, void* stream) {
+  return md_plan_backward_range(P, dfeat, w, gamma, dw, dgamma, dbeta, workspace, 4, 0, stream);
+}
+
+extern "C" int md_version(const char** arch_out) {
+  if (arch_out) *arch_out = "gfx950";
+  return MD_ABI_VERSION;
+}

@@ -1,0 +1,101 @@
+"""ctypes binding of include/mi355x_disrupt.h (the C-ABI boundary of the hot path).
+
+Loading is lazy and LOUD: if the shared library is missing or lacks a symbol the first call raises
+``RuntimeError`` -- the product path never falls back to a CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libmi355x_disrupt.so")
+
+c_float_p = C.POINTER(C.c_float)
+c_void_p = C.c_void_p
+
+
+class MdConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("N", "Ti", "Hi", "Wi", "Cin", "To", "Ho", "Wo", "Cout", "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw")]
+
+
+class MdActView(C.Structure):
+    _fields_ = [("data", c_void_p), ("scale", c_void_p), ("shift", c_void_p), ("slope", C.c_float)]
+
+
+# name -> (restype, argtypes); mirrors include/mi355x_disrupt.h one to one
+_P = c_void_p
+_I32, _I64, _F, _SZ = C.c_int32, C.c_int64, C.c_float, C.c_size_t
+_DESC, _VIEW = C.POINTER(MdConvDesc), C.POINTER(MdActView)
+SIGNATURES = {
+    "md_version": (C.c_int, [C.POINTER(C.c_char_p)]),
+    "md_conv_wpack_fwd_floats": (_SZ, [_DESC]),
+    "md_conv_wpack_dgrad_floats": (_SZ, [_DESC]),
+    "md_conv_pack_weights": (C.c_int, [_DESC, _P, _P, _P, _P]),
+    "md_conv_fwd_stat_blocks": (_I32, [_DESC]),
+    "md_conv_fwd": (C.c_int, [_DESC, _VIEW, _P, _P, _P, _P]),
+    "md_conv_dgrad": (C.c_int, [_DESC, _P, _P, _P, C.c_int, _P]),
+    "md_conv_wgrad": (C.c_int, [_DESC, _VIEW, _P, _P, _P]),
+    "md_bn_finalize": (C.c_int, [_P, _I32, _I32, _I64, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "md_bn_eval_params": (C.c_int, [_I32, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P]),
+    "md_bn_act": (C.c_int, [_VIEW, _I64, _I32, _P, _P]),
+    "md_residual_fwd": (C.c_int, [_VIEW, _VIEW, _F, _I64, _I32, _P, _P]),
+    "md_bn_bwd_blocks": (_I32, [_I64, _I32]),
+    "md_bn_bwd_reduce": (C.c_int, [_P, _VIEW, _VIEW, _F, _P, _P, _I64, _I32, _P, _P]),
+    "md_bn_bwd_finalize": (C.c_int, [_P, _I32, _I32, _I64, _P, _P, _P, _P]),
+    "md_bn_bwd_apply": (C.c_int, [_P, _VIEW, _VIEW, _F, _P, _P, _P, _I64, _I32, _P, _P, _P]),
+    "md_nchw_to_cl": (C.c_int, [_P, _I32, _I32, _I64, _P, _P]),
+    "md_cl_to_nchw": (C.c_int, [_P, _I32, _I32, _I64, _P, _P]),
+    "md_avgpool_fwd": (C.c_int, [_P, _I32, _I32, _I64, _P, _P]),
+    "md_avgpool_bwd": (C.c_int, [_P, _I32, _I32, _I64, _P, _P]),
+    "md_head_save_floats": (_SZ, [_I32, _I32, _I32]),
+    "md_head_fwd": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _F, _F, _F, C.c_int, _P, _P, _P, _P, _P]),
+    "md_head_bwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "md_softmax_loss": (C.c_int, [_I32, _P, _P, _I32, _I32, _P, _P, _F, _P, _P, _P, _P]),
+    "md_plan_create": (C.c_int, [_I32, _I32, _I32, _I32, C.POINTER(_I32), _F, C.POINTER(_P)]),
+    "md_plan_destroy": (None, [_P]),
+    "md_plan_num_units": (_I32, [_P]),
+    "md_plan_unit_desc": (C.c_int, [_P, _I32, _DESC]),
+    "md_plan_workspace_bytes": (_SZ, [_P]),
+    "md_plan_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P]),
+    "md_plan_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "md_plan_backward_range": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P]),
+    "md_plan_feat_dim": (_I32, [_P]),
+}
+
+ERRORS = {-1: "bad shape", -2: "unsupported", -3: "workspace", -4: "kernel launch failed", -5: "null pointer"}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib() -> C.CDLL:
+    """The loaded library with every prototype declared; raises RuntimeError if it cannot be loaded."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        f"MI355X HIP library not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; "
+                        "g.build()'` (or `make -C csrc`). There is no CPU fallback for this path.")
+                try:
+                    L = C.CDLL(LIB_PATH)
+                except OSError as e:  # pragma: no cover
+                    raise RuntimeError(f"cannot load {LIB_PATH}: {e}") from e
+                for name, (res, args) in SIGNATURES.items():
+                    try:
+                        f = getattr(L, name)
+                    except AttributeError as e:
+                        raise RuntimeError(f"{LIB_PATH} does not export {name}") from e
+                    f.restype = res
+                    f.argtypes = args
+                _lib = L
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {ERRORS.get(rc, rc)}")

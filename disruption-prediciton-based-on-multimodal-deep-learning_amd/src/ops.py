@@ -1,0 +1,200 @@
+"""Thin torch-level wrappers over the C ABI (include/mi355x_disrupt.h).
+
+PyTorch is used for device memory and the current HIP stream only; every function here launches
+hand-written gfx950 kernels through ``_native.lib()`` and raises if given a CPU tensor.
+Tensors in the library's internal layout are channels-last ``[N, T, H, W, Cp]`` fp32 with
+``Cp = cpad(C)``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _native as N
+
+
+def cpad(c: int) -> int:
+    return (c + 3) & ~3
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def require_cuda(*tensors: Optional[torch.Tensor]) -> None:
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("mi355x hot path: CPU tensor given; this path runs on the GPU only (no CPU fallback)")
+        if not t.is_contiguous():
+            raise RuntimeError("mi355x hot path: tensor must be contiguous")
+
+
+def f32(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"mi355x hot path: expected float32, got {t.dtype}")
+    return t
+
+
+def make_desc(n, ti, hi, wi, cin, cout, kernel, stride, padding) -> N.MdConvDesc:
+    kt, kh, kw = kernel
+    st, sh, sw = stride
+    pt, ph, pw = padding
+    to = (ti + 2 * pt - kt) // st + 1
+    ho = (hi + 2 * ph - kh) // sh + 1
+    wo = (wi + 2 * pw - kw) // sw + 1
+    return N.MdConvDesc(n, ti, hi, wi, cin, to, ho, wo, cout, kt, kh, kw, st, sh, sw, pt, ph, pw)
+
+
+def view(data: torch.Tensor, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
+         slope: float = 1.0) -> N.MdActView:
+    require_cuda(data, scale, shift)
+    return N.MdActView(data.data_ptr(), None if scale is None else scale.data_ptr(),
+                       None if shift is None else shift.data_ptr(), float(slope))
+
+
+# ----------------------------------------------------------------------------------------- layout
+def to_channels_last(x: torch.Tensor) -> torch.Tensor:
+    """(B,C,T,H,W) -> [B,T,H,W,Cp]"""
+    require_cuda(x); f32(x)
+    B, Cc, T, H, W = x.shape
+    out = torch.empty((B, T, H, W, cpad(Cc)), device=x.device, dtype=torch.float32)
+    N.check(N.lib().md_nchw_to_cl(_p(x), B, Cc, T * H * W, _p(out), _stream()), "md_nchw_to_cl")
+    return out
+
+
+def from_channels_last(x: torch.Tensor, channels: int) -> torch.Tensor:
+    require_cuda(x); f32(x)
+    B, T, H, W, Cp = x.shape
+    assert Cp == cpad(channels)
+    out = torch.empty((B, channels, T, H, W), device=x.device, dtype=torch.float32)
+    N.check(N.lib().md_cl_to_nchw(_p(x), B, channels, T * H * W, _p(out), _stream()), "md_cl_to_nchw")
+    return out
+
+
+# ----------------------------------------------------------------------------------------- conv
+def pack_weights(d: N.MdConvDesc, w: torch.Tensor, want_dgrad: bool = True):
+    require_cuda(w); f32(w)
+    L = N.lib()
+    wf = torch.empty(L.md_conv_wpack_fwd_floats(C.byref(d)), device=w.device, dtype=torch.float32)
+    wd = torch.empty(L.md_conv_wpack_dgrad_floats(C.byref(d)), device=w.device, dtype=torch.float32) if want_dgrad else None
+    N.check(L.md_conv_pack_weights(C.byref(d), _p(w), _p(wf), _p(wd), _stream()), "md_conv_pack_weights")
+    return wf, wd
+
+
+def conv_fwd(d: N.MdConvDesc, x: N.MdActView, wf: torch.Tensor, device, want_stats: bool = True):
+    L = N.lib()
+    y = torch.empty((d.N, d.To, d.Ho, d.Wo, cpad(d.Cout)), device=device, dtype=torch.float32)
+    part = None
+    if want_stats:
+        part = torch.empty((L.md_conv_fwd_stat_blocks(C.byref(d)), 2, cpad(d.Cout)), device=device, dtype=torch.float32)
+    N.check(L.md_conv_fwd(C.byref(d), C.byref(x), _p(wf), _p(y), _p(part), _stream()), "md_conv_fwd")
+    return y, part
+
+
+def conv_dgrad(d: N.MdConvDesc, dy: torch.Tensor, wd: torch.Tensor, out: Optional[torch.Tensor] = None,
+               accumulate: bool = False) -> torch.Tensor:
+    require_cuda(dy, wd, out)
+    if out is None:
+        out = torch.empty((d.N, d.Ti, d.Hi, d.Wi, cpad(d.Cin)), device=dy.device, dtype=torch.float32)
+        accumulate = False
+    N.check(N.lib().md_conv_dgrad(C.byref(d), _p(dy), _p(wd), _p(out), int(accumulate), _stream()), "md_conv_dgrad")
+    return out
+
+
+def conv_wgrad(d: N.MdConvDesc, x: N.MdActView, dy: torch.Tensor) -> torch.Tensor:
+    require_cuda(dy)
+    dw = torch.zeros((d.Cout, d.Cin, d.kt, d.kh, d.kw), device=dy.device, dtype=torch.float32)
+    N.check(N.lib().md_conv_wgrad(C.byref(d), C.byref(x), _p(dy), _p(dw), _stream()), "md_conv_wgrad")
+    return dw
+
+
+# ----------------------------------------------------------------------------------------- batch norm
+def bn_finalize(part: torch.Tensor, Cc: int, count: int, gamma, beta, rmean=None, rvar=None, eps=1e-5, momentum=0.1):
+    require_cuda(part, gamma, beta, rmean, rvar)
+    Cp = cpad(Cc)
+    st = torch.empty((4, Cp), device=part.device, dtype=torch.float32)   # mean, invstd, scale, shift
+    N.check(N.lib().md_bn_finalize(_p(part), part.shape[0], Cc, count, _p(gamma), _p(beta), eps, momentum, _p(rmean),
+                                   _p(rvar), _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]), _stream()), "md_bn_finalize")
+    return st
+
+
+def bn_act(v: N.MdActView, like: torch.Tensor, Cc: int) -> torch.Tensor:
+    out = torch.empty_like(like)
+    rows = like.numel() // like.shape[-1]
+    N.check(N.lib().md_bn_act(C.byref(v), rows, Cc, _p(out), _stream()), "md_bn_act")
+    return out
+
+
+def residual_fwd(skip: N.MdActView, main: N.MdActView, alpha: float, like: torch.Tensor, Cc: int) -> torch.Tensor:
+    out = torch.empty_like(like)
+    rows = like.numel() // like.shape[-1]
+    N.check(N.lib().md_residual_fwd(C.byref(skip), C.byref(main), float(alpha), rows, Cc, _p(out), _stream()),
+            "md_residual_fwd")
+    return out
+
+
+def bn_backward(dA: torch.Tensor, main: N.MdActView, st: torch.Tensor, Cc: int, skip: Optional[N.MdActView] = None,
+                alpha: float = 1.0):
+    """Returns (d_raw, dS or None, dgamma, dbeta)."""
+    require_cuda(dA, st)
+    L = N.lib()
+    rows = dA.numel() // dA.shape[-1]
+    Cp = cpad(Cc)
+    nb = L.md_bn_bwd_blocks(rows, Cc)
+    part = torch.empty((nb, 2, Cp), device=dA.device, dtype=torch.float32)
+    sk = C.byref(skip) if skip is not None else None
+    N.check(L.md_bn_bwd_reduce(_p(dA), C.byref(main), sk, float(alpha), _p(st[0]), _p(st[1]), rows, Cc, _p(part), _stream()),
+            "md_bn_bwd_reduce")
+    dgamma = torch.empty(Cc, device=dA.device, dtype=torch.float32)
+    dbeta = torch.empty(Cc, device=dA.device, dtype=torch.float32)
+    coef = torch.empty((2, Cp), device=dA.device, dtype=torch.float32)
+    N.check(L.md_bn_bwd_finalize(_p(part), nb, Cc, rows, _p(dgamma), _p(dbeta), _p(coef), _stream()), "md_bn_bwd_finalize")
+    d_raw = torch.empty_like(dA)
+    dS = torch.empty_like(dA) if skip is not None else None
+    N.check(L.md_bn_bwd_apply(_p(dA), C.byref(main), sk, float(alpha), _p(st[0]), _p(st[1]), _p(coef), rows, Cc, _p(d_raw),
+                              _p(dS), _stream()), "md_bn_bwd_apply")
+    return d_raw, dS, dgamma, dbeta
+
+
+# ----------------------------------------------------------------------------------------- pool / head / loss
+def avgpool_fwd(x: torch.Tensor, Cc: int) -> torch.Tensor:
+    require_cuda(x)
+    B = x.shape[0]
+    thw = x.shape[1] * x.shape[2] * x.shape[3]
+    feat = torch.empty((B, Cc), device=x.device, dtype=torch.float32)
+    N.check(N.lib().md_avgpool_fwd(_p(x), B, Cc, thw, _p(feat), _stream()), "md_avgpool_fwd")
+    return feat
+
+
+def avgpool_bwd(dfeat: torch.Tensor, shape: Sequence[int]) -> torch.Tensor:
+    require_cuda(dfeat)
+    B, T, H, W, Cp = shape
+    dx = torch.empty(tuple(shape), device=dfeat.device, dtype=torch.float32)
+    N.check(N.lib().md_avgpool_bwd(_p(dfeat), B, dfeat.shape[1], T * H * W, _p(dx), _stream()), "md_avgpool_bwd")
+    return dx
+
+
+KIND = {"focal": 0, "ldam": 1, "ce": 2}
+
+
+def softmax_loss(kind: str, logits: torch.Tensor, target: torch.Tensor, weight: Optional[torch.Tensor],
+                 margins: Optional[torch.Tensor], gamma_or_s: float, want_grad: bool = True):
+    """Returns (loss[1], dlogits or None, pred int64[B])."""
+    require_cuda(logits, target, weight, margins); f32(logits)
+    if target.dtype != torch.int64:
+        raise RuntimeError("target must be int64")
+    B, K = logits.shape
+    loss = torch.empty(1, device=logits.device, dtype=torch.float32)
+    dl = torch.empty_like(logits) if want_grad else None
+    pred = torch.empty(B, device=logits.device, dtype=torch.int64)
+    N.check(N.lib().md_softmax_loss(KIND[kind], _p(logits), _p(target), B, K, _p(weight), _p(margins), float(gamma_or_s),
+                                    _p(loss), _p(dl), _p(pred), _stream()), "md_softmax_loss")
+    return loss, dl, pred

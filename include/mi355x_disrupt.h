@@ -1,0 +1,194 @@
+/*
+ * mi355x_disrupt.h -- C ABI of the MI355X (gfx950) hot path of the KSTAR disruption predictor.
+ *
+ * The reference (ZINZINBIN/Disruption-Prediciton-based-on-Multimodal-Deep-Learning) is pure
+ * Python/PyTorch and defines no FFI; its boundary for this path is the nn.Module protocol
+ * (SURVEY.md section 8b).  This header is the C-ABI layer underneath the Python mirror of that protocol:
+ * every entry point names the reference construct it replaces (file:line, relative to the
+ * reference root).  Conventions:
+ *   - plain pointers and sizes only, no torch / HIP C++ types: `stream` is a hipStream_t passed as void*;
+ *   - all data pointers are caller-owned DEVICE memory, fp32 unless stated;
+ *   - returns 0 on success or a negative MD_ERR_* code; never throws, never allocates device memory
+ *     (plans excepted: md_plan_create allocates host metadata only), never synchronises the device;
+ *   - re-entrant across host threads and streams (backward is called from the autograd thread).
+ *
+ * Activation layout inside the library: channels-last [N][T][H][W][Cp], Cp = channels rounded up
+ * to a multiple of 4 (16-byte pixels), pad channels always zero.  md_nchw_to_cl / md_cl_to_nchw
+ * convert at the (B,C,T,H,W) boundary of the reference (src/dataset.py:229-230).
+ */
+#ifndef MI355X_DISRUPT_H
+#define MI355X_DISRUPT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MD_OK 0
+#define MD_ERR_BAD_SHAPE (-1)
+#define MD_ERR_UNSUPPORTED (-2)
+#define MD_ERR_WORKSPACE (-3)
+#define MD_ERR_LAUNCH (-4)
+#define MD_ERR_NULL (-5)
+
+/* Library identity: returns the ABI version; *arch_out (optional) receives "gfx950". */
+int md_version(const char** arch_out);
+
+/* ------------------------------------------------------------------------------------------------
+ * Convolution as implicit GEMM on the matrix cores (replaces nn.Conv3d fwd/bwd as used by
+ * Conv3dBlock, src/models/R2Plus1D.py:44-51; covers both factors of SpatioTemporalConv :139-140,
+ * :156-157 -- (1,k,k) spatial and (k,1,1) temporal are the same kernel with different taps).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct MdConvDesc {
+  int32_t N, Ti, Hi, Wi, Cin;   /* input  (B, Cin, Ti, Hi, Wi) of the reference conv; N = batch         */
+  int32_t To, Ho, Wo, Cout;     /* output (B, Cout, To, Ho, Wo)                                          */
+  int32_t kt, kh, kw;           /* kernel_size                                                            */
+  int32_t st, sh, sw;           /* stride                                                                 */
+  int32_t pt, ph, pw;           /* padding                                                                */
+} MdConvDesc;
+
+/* "BN-on-read" view of an activation: value = leaky(x*scale[c] + shift[c], slope) applied while the
+ * tensor is staged into LDS (fuses BatchNorm3d + LeakyReLU of Conv3dBlock.forward, R2Plus1D.py:56-58,
+ * into the consumer).  scale == NULL means the tensor is used as stored. */
+typedef struct MdActView {
+  const float* data;   /* channels-last activation                                                       */
+  const float* scale;  /* [Cp] or NULL                                                                   */
+  const float* shift;  /* [Cp] or NULL                                                                   */
+  float slope;         /* LeakyReLU negative slope                                                       */
+} MdActView;
+
+static inline int32_t md_cpad(int32_t c) { return (c + 3) & ~3; }
+
+/* Packed-weight sizes (floats): forward GEMM operand [Cout16][Kp] and dgrad operand [Cin16][Kp']. */
+size_t md_conv_wpack_fwd_floats(const MdConvDesc* d);
+size_t md_conv_wpack_dgrad_floats(const MdConvDesc* d);
+/* Pack the reference-layout weight (Cout,Cin,kt,kh,kw) into either operand (tiny kernel). */
+int md_conv_pack_weights(const MdConvDesc* d, const float* w, float* wpack_fwd, float* wpack_dgrad, void* stream);
+
+/* Number of row-blocks the forward kernel uses = rows of the BatchNorm partial-statistics buffer. */
+int32_t md_conv_fwd_stat_blocks(const MdConvDesc* d);
+
+/* y_raw = conv(x_view); if stat_partial != NULL the epilogue also writes per-row-block partial
+ * (sum, sum of squares) of y_raw per output channel: [blocks][2][md_cpad(Cout)]  (first half of
+ * BatchNorm3d's batch statistics, R2Plus1D.py:53). */
+int md_conv_fwd(const MdConvDesc* d, const MdActView* x, const float* wpack_fwd, float* y_raw,
+                float* stat_partial, void* stream);
+
+/* dx (+)= conv_transpose(dy_raw): gradient w.r.t. the (activated) conv input.  accumulate != 0 adds
+ * into dx (used where a residual skip and a conv share their input, R2Plus1D.py:181-187). */
+int md_conv_dgrad(const MdConvDesc* d, const float* dy_raw, const float* wpack_dgrad, float* dx,
+                  int accumulate, void* stream);
+
+/* dw (reference layout, must be zeroed by the caller: md_conv_wgrad accumulates with float atomics)
+ * += x_view^T * dy_raw. */
+int md_conv_wgrad(const MdConvDesc* d, const MdActView* x, const float* dy_raw, float* dw, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BatchNorm3d (train mode) + LeakyReLU + residual: everything between two convolutions
+ * (R2Plus1D.py:53-58, :179-187).
+ * ---------------------------------------------------------------------------------------------- */
+/* Second half of the batch statistics: reduce the conv epilogue's partials in fixed order (fp64),
+ * produce mean / invstd / scale=gamma*invstd / shift=beta-mean*scale (all [Cp]) and update
+ * running_mean / running_var (momentum 0.1, unbiased variance) like nn.BatchNorm3d. running_* may be NULL. */
+int md_bn_finalize(const float* stat_partial, int32_t blocks, int32_t C, int64_t count,
+                   const float* gamma, const float* beta, float eps, float momentum,
+                   float* running_mean, float* running_var,
+                   float* mean, float* invstd, float* scale, float* shift, void* stream);
+
+/* Eval-mode counterpart (model.eval(), src/train.py:104): scale/shift from the running statistics. */
+int md_bn_eval_params(int32_t C, const float* gamma, const float* beta, const float* running_mean,
+                      const float* running_var, float eps, float* mean, float* invstd, float* scale,
+                      float* shift, void* stream);
+
+/* out = view(x)  (materialise BatchNorm+LeakyReLU); rows = N*T*H*W pixels, C real channels. */
+int md_bn_act(const MdActView* x, int64_t rows, int32_t C, float* out, void* stream);
+
+/* z = leaky(view(skip) + view(main), alpha): SpatioTemporalResBlock.forward's `self.relu(x + res)`,
+ * R2Plus1D.py:187. */
+int md_residual_fwd(const MdActView* skip, const MdActView* main, float alpha, int64_t rows, int32_t C,
+                    float* z, void* stream);
+
+/* BatchNorm backward, split like the forward:
+ *  (1) md_bn_bwd_reduce : partial sums of g and g*xhat per channel, g = dA * leaky'(pre-activation).
+ *      With `skip` != NULL the unit closes a residual block: dA := dZ * leaky'_alpha(view(skip)+view(main)).
+ *  (2) md_bn_bwd_finalize: dgamma, dbeta and the per-channel coefficients of (3).
+ *  (3) md_bn_bwd_apply  : d_raw = scale * (g - mean(g) - xhat * mean(g*xhat)); may run in place
+ *      (d_raw == dA).  In the residual form it also writes dS = dZ*leaky'_alpha(...) (may alias dZ).
+ */
+int32_t md_bn_bwd_blocks(int64_t rows, int32_t C);
+int md_bn_bwd_reduce(const float* dA, const MdActView* main, const MdActView* skip, float alpha,
+                     const float* mean, const float* invstd, int64_t rows, int32_t C,
+                     float* partial /* [blocks][2][Cp] */, void* stream);
+int md_bn_bwd_finalize(const float* partial, int32_t blocks, int32_t C, int64_t count,
+                       float* dgamma, float* dbeta, float* coef /* [2][Cp]: mean(g), mean(g*xhat) */,
+                       void* stream);
+int md_bn_bwd_apply(const float* dA, const MdActView* main, const MdActView* skip, float alpha,
+                    const float* mean, const float* invstd, const float* coef, int64_t rows, int32_t C,
+                    float* d_raw, float* dS, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Boundary layout conversion, pooling, classifier head, losses.
+ * ---------------------------------------------------------------------------------------------- */
+/* (B,C,T,H,W) fp32 planar (src/dataset.py:229-230) <-> channels-last with pitch md_cpad(C). */
+int md_nchw_to_cl(const float* x, int32_t B, int32_t C, int64_t thw, float* out, void* stream);
+int md_cl_to_nchw(const float* x, int32_t B, int32_t C, int64_t thw, float* out, void* stream);
+
+/* AdaptiveAvgPool3d(1) + view (R2Plus1D.py:215,224-225): feat[B][C] = mean over thw of x[B][thw][Cp]. */
+int md_avgpool_fwd(const float* x, int32_t B, int32_t C, int64_t thw, float* feat, void* stream);
+int md_avgpool_bwd(const float* dfeat, int32_t B, int32_t C, int64_t thw, float* dx, void* stream);
+
+/* Classifier head Linear(D->Hd) + BatchNorm1d(Hd) + ELU(alpha) + Linear(Hd->K), R2Plus1D.py:243-248.
+ * save: workspace of md_head_save_floats() floats kept for backward. */
+size_t md_head_save_floats(int32_t B, int32_t D, int32_t Hd);
+int md_head_fwd(const float* feat, int32_t B, int32_t D, int32_t Hd, int32_t K,
+                const float* w0, const float* b0, const float* gamma, const float* beta,
+                const float* w1, const float* b1, float alpha, float eps, float momentum, int training,
+                float* running_mean, float* running_var, float* logits, float* save, void* stream);
+int md_head_bwd(const float* dlogits, const float* feat, int32_t B, int32_t D, int32_t Hd, int32_t K,
+                const float* w0, const float* gamma, const float* w1, float alpha, const float* save,
+                float* dfeat, float* dw0, float* db0, float* dgamma, float* dbeta, float* dw1, float* db1,
+                void* stream);
+
+/* Fused softmax + loss (src/loss.py): kind 0 = FocalLoss (:14-34, sum), 1 = LDAMLoss (:37-69,
+ * weighted mean), 2 = CELoss (:71-81, sum).  Emits the scalar loss, d loss / d logits (for an upstream
+ * gradient of 1; the caller scales) and pred = argmax softmax (src/train.py:70) in one launch.  class_weight / margins may be NULL (ones / zeros).  target is int64. */
+int md_softmax_loss(int32_t kind, const float* logits, const int64_t* target, int32_t B, int32_t K,
+                    const float* class_weight, const float* margins, float gamma_or_s,
+                    float* loss, float* dlogits, int64_t* pred, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Whole-trunk executor: R2Plus1DNet.forward / backward (R2Plus1D.py:207-226) as one plan.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct MdPlan MdPlan;
+/* layer_sizes[4] as in R2Plus1DNet(layer_sizes) :208; alpha = LeakyReLU slope of the stem and of the
+ * block-closing activations (:210-214). */
+int md_plan_create(int32_t B, int32_t T, int32_t H, int32_t W, const int32_t* layer_sizes, float alpha,
+                   MdPlan** out);
+void md_plan_destroy(MdPlan* p);
+/* Number of conv units (Conv3dBlock instances) and their order = the reference's module order
+ * (stem spatial, stem temporal, then per block conv1.s, conv1.t, conv2.s, conv2.t[, downsample.s, .t]). */
+int32_t md_plan_num_units(const MdPlan* p);
+int md_plan_unit_desc(const MdPlan* p, int32_t i, MdConvDesc* out);
+/* Device memory the plan needs (bytes): activations kept for backward + scratch. */
+size_t md_plan_workspace_bytes(const MdPlan* p);
+/* Parameter / gradient / buffer tables: arrays of device pointers indexed by unit:
+ *   w[i] (Cout,Cin,kt,kh,kw), gamma[i], beta[i], running_mean[i], running_var[i] (may be NULL). */
+int md_plan_forward(MdPlan* p, const float* x_ncthw, const float* const* w, const float* const* gamma,
+                    const float* const* beta, float* const* running_mean, float* const* running_var,
+                    int training, float* feat /* [B][C_out] */, void* workspace, void* stream);
+int md_plan_backward(MdPlan* p, const float* dfeat, const float* const* w, const float* const* gamma,
+                     float* const* dw, float* const* dgamma, float* const* dbeta,
+                     void* workspace, void* stream);
+/* Segmented backward for overlap with gradient all-reduce (src/distributed.py DP loop): runs the
+ * backward of stages [stage_hi .. stage_lo] (4 = conv5 ... 0 = stem). */
+int md_plan_backward_range(MdPlan* p, const float* dfeat, const float* const* w, const float* const* gamma,
+                           float* const* dw, float* const* dgamma, float* const* dbeta,
+                           void* workspace, int32_t stage_hi, int32_t stage_lo, void* stream);
+int32_t md_plan_feat_dim(const MdPlan* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355X_DISRUPT_H */

@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: R(2+1)D `[1,2,2,1]` training step on synthetic IVIS-shaped clips.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one per-GPU batch (B=8, 3, 21, 128, 128) already resident in HBM:
+forward + FocalLoss + backward (+ gradient all-reduce over RCCL when N>1) + clip_grad_norm(1.0) + AdamW, i.e. the
+body of the reference's train_per_epoch (src/train.py:40-66).  Rank 0 prints ONE JSON line (see DESIGN.md for the
+field definitions, the roofline accounting and the cpu_baseline sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "disruption-prediciton-based-on-multimodal-deep-learning_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+B_PER_GPU, T, S = 8, 21, 128
+LAYERS, ALPHA = [1, 2, 2, 1], 0.01
+ALG_BYTES_PER_CLIP_FP32 = 951.9e6      # ideal-fusion conv I/O, fwd+bwd, fp32 storage
+ALG_FLOP_PER_CLIP = 68.24e9            # 3 x 22.75 GFLOP
+PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_batch(device, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randint(0, 256, (B_PER_GPU, 3, T, S, S), generator=g).float()
+    x -= torch.tensor([90.0, 98.0, 102.0]).view(1, 3, 1, 1, 1)       # BGR means, src/dataset.py:201-205
+    y = (torch.rand(B_PER_GPU, generator=g) >= 0.05).long()
+    y[0], y[1] = 0, 1                                                  # both classes present
+    return x.to(device), y.to(device)
+
+
+def cpu_baseline(steps=2, warmup=1):
+    """The oracle (CPU restatement of the reference, oracle/) timed on the host cores: same step definition,
+    same shapes, bounded sample.  Reported beside the GPU number; never the thing optimised."""
+    from oracle import losses as ol, r2plus1d as orc, step as ostep
+    # the GPU box gives one GPU's share of the host (16 cores); more threads than cores only thrash
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except Exception:
+        ncores = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(16, ncores)))
+    params, bufs = orc.synth_state(LAYERS, 1234, ALPHA)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    opt = torch.optim.AdamW(list(leaves.values()), lr=2e-4)
+    x = orc.synth_clip(B_PER_GPU, T, S, 1234)
+    y = orc.synth_labels(B_PER_GPU, 1234)
+    one = torch.ones(2)
+
+    def step():
+        opt.zero_grad()
+        out = orc.classifier_forward(x, leaves, bufs, LAYERS, ALPHA, True)
+        loss = ol.focal_loss(out, y, one, 2.0)
+        loss.backward()
+        ostep.clip_grad_norm([p.grad for p in leaves.values()], 1.0)
+        opt.step()
+
+    for _ in range(warmup):
+        step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = time.perf_counter() - t0
+    return {"value": round(B_PER_GPU * steps / dt, 3), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} full steps (after {warmup} warm-up) of the same B=8 (3,21,128,128) workload, fp32, "
+                      f"oracle/ on torch-CPU, anomaly mode off"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    device = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from src.models.R2Plus1D import R2Plus1DClassifier
+    from src.loss import FocalLoss
+    from src.distributed import GradAllReducer, broadcast_module_state
+
+    torch.manual_seed(1234)
+    model = R2Plus1DClassifier(input_size=(3, T, S, S), num_classes=2, layer_sizes=LAYERS, alpha=ALPHA).to(device)
+    model.train()
+    reducer = None
+    if world > 1:
+        broadcast_module_state(model, 0)
+        reducer = GradAllReducer(model)
+    loss_fn = FocalLoss(weight=torch.ones(2), gamma=2.0)
+    try:
+        opt = torch.optim.AdamW(model.parameters(), lr=2e-4, fused=True)
+    except Exception:
+        opt = torch.optim.AdamW(model.parameters(), lr=2e-4)
+    x, y = synth_batch(device, 1234 + rank)
+    finite = torch.ones((), device=device)
+
+    def step():
+        nonlocal finite
+        opt.zero_grad(set_to_none=True)
+        logits = model(x)
+        loss = loss_fn(logits, y)
+        loss.backward()
+        if reducer is not None:
+            reducer.reduce_rest()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        finite = finite * torch.isfinite(loss.detach()).float()       # checked after the timed region, no host sync here
+
+    for _ in range(args.warmup):
+        step()
+    plan = model.res2plus1d._plans[(B_PER_GPU, T, S, S)]
+    plan.profile_enable(True)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = plan.profile_read()
+    plan.profile_enable(False)
+    if float(finite.item()) != 1.0:
+        raise SystemExit("non-finite loss inside the timed region")
+    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        clips = B_PER_GPU * world * args.steps
+        value = clips / dt
+        names = ["k_conv_gemm(forward)", "k_conv_gemm(data-gradient)", "k_conv_wgrad"]
+        kern = []
+        for (ms, n, fl), nm in zip(prof, names):
+            if n:
+                kern.append({"kernel": nm, "launches": int(n), "avg_ms": ms / n, "total_ms_per_step": ms / args.steps,
+                             "tflops": fl / (ms * 1e-3) / 1e12})
+        # the dominant kernel (by time) is k_conv_gemm: forward + data-gradient launches are the same kernel
+        g_ms = prof[0][0] + prof[1][0]; g_n = prof[0][1] + prof[1][1]; g_fl = prof[0][2] + prof[1][2]
+        w_ms, w_n, w_fl = prof[2]
+        if g_ms >= w_ms:
+            dom, d_ms, d_n, d_fl = "k_conv_gemm", g_ms, g_n, g_fl
+        else:
+            dom, d_ms, d_n, d_fl = "k_conv_wgrad", w_ms, w_n, w_fl
+        achieved = d_fl / (d_ms * 1e-3) / 1e12
+        out = {
+            "metric": "clips/sec (fwd+bwd) R2Plus1D T=21 128x128", "value": round(value, 2), "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "R2Plus1D layer_sizes=[1,2,2,1] alpha=0.01, per-GPU clips (8,3,21,128,128) fp32, "
+                                   "forward+FocalLoss(gamma=2)+backward+clip_grad_norm(1.0)+AdamW(2e-4), BN in train mode",
+                       "per_gpu_batch": B_PER_GPU, "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "kernel": dom,
+                         "launches": int(d_n), "avg_launch_ms": round(d_ms / max(1, d_n), 5),
+                         "alg_flop_per_launch": d_fl / max(1, d_n)},
+            "kernels": kern,
+            "whole_step": {"alg_tflops": round(value / world * ALG_FLOP_PER_CLIP / 1e12, 2),
+                           "alg_hbm_gbs_fp32": round(value / world * ALG_BYTES_PER_CLIP_FP32 / 1e9, 1),
+                           "hbm_frac_of_8TBs": round(value / world * ALG_BYTES_PER_CLIP_FP32 / 1e9 / PEAK_HBM_GBS, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -30,7 +30,18 @@ struct Block {
 };
 struct ZT { int C; int64_t rows; size_t off; };
 
+// Optional per-kernel-class timing with HIP events on the launch stream (used by bench.py's roofline leg).
+enum { KC_FWD = 0, KC_DGRAD = 1, KC_WGRAD = 2, KC_N = 3 };
+struct Prof {
+  bool on = false;
+  std::vector<hipEvent_t> pool;   // pairs (start, stop)
+  std::vector<int> cls;           // class of pair i
+  std::vector<double> flop;       // algorithmic FLOPs of pair i
+  size_t used = 0;                // pairs recorded since the last read
+};
+
 struct MdPlan {
+  Prof prof;
   int B, T, H, W;
   float alpha;
   std::vector<Unit> units;
@@ -133,7 +144,11 @@ extern "C" int md_plan_create(int32_t B, int32_t T, int32_t H, int32_t W, const 
   return MD_OK;
 }
 
-extern "C" void md_plan_destroy(MdPlan* p) { delete p; }
+extern "C" void md_plan_destroy(MdPlan* p) {
+  if (!p) return;
+  for (hipEvent_t e : p->prof.pool) (void)hipEventDestroy(e);
+  delete p;
+}
 extern "C" int32_t md_plan_num_units(const MdPlan* p) { return p ? (int32_t)p->units.size() : 0; }
 extern "C" int md_plan_unit_desc(const MdPlan* p, int32_t i, MdConvDesc* out) {
   if (!p || !out) return MD_ERR_NULL;
@@ -145,6 +160,49 @@ extern "C" size_t md_plan_workspace_bytes(const MdPlan* p) { return p ? p->total
 extern "C" int32_t md_plan_feat_dim(const MdPlan* p) { return p ? p->feat_dim : 0; }
 
 #define RC(x) do { int rc__ = (x); if (rc__ != MD_OK) return rc__; } while (0)
+
+static double unit_flops(const Unit& u) {
+  return 2.0 * (double)u.rows * u.d.Cout * u.d.Cin * u.d.kt * u.d.kh * u.d.kw;
+}
+// bracket one launch with events; a no-op unless profiling is enabled
+struct ProfScope {
+  MdPlan* P; hipStream_t s; size_t idx; bool on;
+  ProfScope(MdPlan* P_, int cls, double flop, void* stream) : P(P_), s((hipStream_t)stream), idx(0), on(P_->prof.on) {
+    if (!on) return;
+    Prof& pr = P->prof;
+    if (pr.used * 2 + 2 > pr.pool.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+      pr.pool.push_back(a); pr.pool.push_back(b); pr.cls.push_back(0); pr.flop.push_back(0.0);
+    }
+    idx = pr.used++;
+    pr.cls[idx] = cls; pr.flop[idx] = flop;
+    (void)hipEventRecord(pr.pool[2 * idx], s);
+  }
+  ~ProfScope() { if (on) (void)hipEventRecord(P->prof.pool[2 * idx + 1], s); }
+};
+
+extern "C" int md_plan_profile_enable(MdPlan* P, int enable) {
+  if (!P) return MD_ERR_NULL;
+  P->prof.on = enable != 0;
+  P->prof.used = 0;
+  return MD_OK;
+}
+// Sum of event-measured durations (ms), launch counts and algorithmic FLOPs per class since the last read
+// (classes: 0 conv forward, 1 conv data-gradient, 2 conv weight-gradient).  Synchronises on the recorded events.
+extern "C" int md_plan_profile_read(MdPlan* P, double* ms, int64_t* launches, double* flops) {
+  if (!P || !ms || !launches || !flops) return MD_ERR_NULL;
+  for (int c = 0; c < KC_N; ++c) { ms[c] = 0.0; launches[c] = 0; flops[c] = 0.0; }
+  Prof& pr = P->prof;
+  for (size_t i = 0; i < pr.used; ++i) {
+    if (hipEventSynchronize(pr.pool[2 * i + 1]) != hipSuccess) return MD_ERR_LAUNCH;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, pr.pool[2 * i], pr.pool[2 * i + 1]) != hipSuccess) return MD_ERR_LAUNCH;
+    ms[pr.cls[i]] += t; launches[pr.cls[i]] += 1; flops[pr.cls[i]] += pr.flop[i];
+  }
+  pr.used = 0;
+  return MD_OK;
+}
 
 static MdActView unit_out_view(const MdPlan* P, float* ws, int ui) {
   const Unit& u = P->units[ui];
@@ -173,7 +231,8 @@ extern "C" int md_plan_forward(MdPlan* P, const float* x, const float* const* w,
     MdActView in = unit_in_view(P, ws, (int)i);
     float* st = ws + u.stat_off;
     if (training) {
-      RC(md_conv_fwd(&u.d, &in, ws + u.wf_off, ws + u.raw_off, ws + P->part_off, stream));
+      { ProfScope ps(P, KC_FWD, unit_flops(u), stream);
+        RC(md_conv_fwd(&u.d, &in, ws + u.wf_off, ws + u.raw_off, ws + P->part_off, stream)); }
       RC(md_bn_finalize(ws + P->part_off, md_conv_fwd_stat_blocks(&u.d), u.d.Cout, u.rows, gamma[i], beta[i], 1e-5f, 0.1f,
                         rmean ? rmean[i] : nullptr, rvar ? rvar[i] : nullptr, st, st + u.Cp, st + 2 * u.Cp, st + 3 * u.Cp,
                         stream));
@@ -221,8 +280,12 @@ static int unit_backward(MdPlan* P, float* ws, int ui, int gb, int dxb, int accu
   const size_t wn = (size_t)u.d.Cout * u.d.Cin * u.d.kt * u.d.kh * u.d.kw;
   if (hipMemsetAsync(dw[ui], 0, wn * 4, (hipStream_t)stream) != hipSuccess) return MD_ERR_LAUNCH;
   MdActView in = unit_in_view(P, ws, ui);
-  RC(md_conv_wgrad(&u.d, &in, G, dw[ui], stream));
-  if (dxb >= 0) RC(md_conv_dgrad(&u.d, G, ws + u.wd_off, ws + P->g_off[dxb], accumulate, stream));
+  { ProfScope ps(P, KC_WGRAD, unit_flops(u), stream);
+    RC(md_conv_wgrad(&u.d, &in, G, dw[ui], stream)); }
+  if (dxb >= 0) {
+    ProfScope ps(P, KC_DGRAD, unit_flops(u), stream);
+    RC(md_conv_dgrad(&u.d, G, ws + u.wd_off, ws + P->g_off[dxb], accumulate, stream));
+  }
   return MD_OK;
 }
 

@@ -63,6 +63,8 @@ SIGNATURES = {
     "md_plan_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "md_plan_backward_range": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P]),
     "md_plan_feat_dim": (_I32, [_P]),
+    "md_plan_profile_enable": (C.c_int, [_P, C.c_int]),
+    "md_plan_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
 }
 
 ERRORS = {-1: "bad shape", -2: "unsupported", -3: "workspace", -4: "kernel launch failed", -5: "null pointer"}

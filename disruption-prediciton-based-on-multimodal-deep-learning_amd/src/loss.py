@@ -1,0 +1,94 @@
+"""Focal / LDAM / CE losses -- MI355X-native mirror of the reference's ``src/loss.py``.
+
+Same classes, constructor arguments, ``forward(input, target)``, ``update_weight`` and ``model_type``
+attribute.  Each forward is ONE fused HIP launch (``md_softmax_loss``) producing the scalar loss, the
+logit gradient and ``pred = argmax softmax`` (kept on ``self.last_pred`` so the training loop's
+bookkeeping, src/train.py:70, needs no second softmax pass).
+Reference anchors: FocalLoss loss.py:14-34 (sum), LDAMLoss :37-69 (weighted mean), CELoss :71-81 (sum).
+"""
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class _SoftmaxLossFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, weight, margins, kind, gs, owner):
+        logits = logits.contiguous().float()
+        target = target.contiguous().view(-1)
+        loss, dl, pred = ops.softmax_loss(kind, logits, target, weight, margins, gs, want_grad=True)
+        if owner is not None:
+            owner.last_pred = pred
+        ctx.save_for_backward(dl)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None, None, None, None, None, None
+
+
+def _dev_weight(weight, device):
+    if weight is None:
+        return None
+    return weight.to(device=device, dtype=torch.float32).contiguous()
+
+
+class FocalLoss(nn.Module):
+    def __init__(self, weight: Optional[torch.Tensor] = None, gamma: float = 2.0):
+        super().__init__()
+        assert gamma >= 0, "gamma should be positive"
+        self.model_type = "Focal"
+        self.gamma = gamma
+        self.weight = weight
+        self.last_pred = None
+
+    def update_weight(self, weight: Optional[torch.Tensor] = None):
+        self.weight = weight
+
+    def forward(self, input: torch.Tensor, target: torch.Tensor):
+        return _SoftmaxLossFunction.apply(input, target, _dev_weight(self.weight, input.device), None, "focal",
+                                          float(self.gamma), self)
+
+
+class LDAMLoss(nn.Module):
+    def __init__(self, cls_num_list: Optional[List], max_m: float = 0.5, weight: Optional[torch.Tensor] = None, s: int = 30):
+        super().__init__()
+        assert s > 0, "s should be positive"
+        self.model_type = "LDAM"
+        self.s = s
+        self.max_m = max_m
+        self.weight = weight
+        self.last_pred = None
+        if cls_num_list:
+            self.update_m_list(cls_num_list)
+
+    def update_weight(self, weight: Optional[torch.Tensor] = None):
+        self.weight = weight
+
+    def update_m_list(self, cls_num_list: List):
+        m_list = 1.0 / np.sqrt(np.sqrt(cls_num_list))
+        m_list = m_list * (self.max_m / np.max(m_list))
+        self.m_list = torch.FloatTensor(m_list)
+
+    def forward(self, x: torch.Tensor, target: torch.Tensor):
+        m = self.m_list.to(device=x.device, dtype=torch.float32).contiguous()
+        return _SoftmaxLossFunction.apply(x, target, _dev_weight(self.weight, x.device), m, "ldam", float(self.s), self)
+
+
+class CELoss(nn.Module):
+    def __init__(self, weight: Optional[torch.Tensor] = None):
+        super().__init__()
+        self.model_type = "CE"
+        self.weight = weight
+        self.last_pred = None
+
+    def update_weight(self, weight: Optional[torch.Tensor] = None):
+        self.weight = weight
+
+    def forward(self, x: torch.Tensor, target: torch.Tensor):
+        return _SoftmaxLossFunction.apply(x, target, _dev_weight(self.weight, x.device), None, "ce", 0.0, self)

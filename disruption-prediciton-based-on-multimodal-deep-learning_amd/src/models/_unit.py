@@ -1,0 +1,106 @@
+"""Composable per-unit autograd bridges over the C ABI: one Conv3d+BatchNorm3d+LeakyReLU unit
+(reference Conv3dBlock, src/models/R2Plus1D.py:25-58) and the classifier head (:243-248).
+
+The R(2+1)D trunk does not use these (it runs as one executor plan, ``_plan.py``); they exist so that
+sub-modules called on their own -- and other encoders assembled from the same unit -- run on the same
+gfx950 kernels.  Tensors cross this boundary in the reference's (B,C,T,H,W) layout.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from .. import _native as N
+from .. import ops
+
+
+class ConvBnLeakyFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, rmean, rvar, stride, padding, slope, training, eps, momentum):
+        ops.require_cuda(x, w, gamma, beta)
+        B, Cin, T, H, W = x.shape
+        Cout = w.shape[0]
+        d = ops.make_desc(B, T, H, W, Cin, Cout, tuple(w.shape[2:]), tuple(stride), tuple(padding))
+        xcl = ops.to_channels_last(x.contiguous().float())
+        wf, wd = ops.pack_weights(d, w.contiguous(), want_dgrad=training)
+        y, part = ops.conv_fwd(d, ops.view(xcl), wf, x.device, want_stats=training)
+        rows = y.numel() // y.shape[-1]
+        if training:
+            st = ops.bn_finalize(part, Cout, rows, gamma, beta, rmean, rvar, eps, momentum)
+        else:
+            st = torch.empty((4, ops.cpad(Cout)), device=x.device, dtype=torch.float32)
+            N.check(N.lib().md_bn_eval_params(Cout, ops._p(gamma), ops._p(beta), ops._p(rmean), ops._p(rvar), eps,
+                                              ops._p(st[0]), ops._p(st[1]), ops._p(st[2]), ops._p(st[3]), ops._stream()),
+                    "md_bn_eval_params")
+        a = ops.bn_act(ops.view(y, st[2], st[3], slope), y, Cout)
+        out = ops.from_channels_last(a, Cout)
+        if training:
+            ctx.d = d
+            ctx.slope = slope
+            ctx.save_for_backward(xcl, y, st, wd)
+        ctx.training = training
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if not ctx.training:
+            raise RuntimeError("mi355x hot path: backward through an eval-mode BatchNorm unit is not supported")
+        xcl, y, st, wd = ctx.saved_tensors
+        d = ctx.d
+        dA = ops.to_channels_last(dout.contiguous().float())
+        d_raw, _, dgamma, dbeta = ops.bn_backward(dA, ops.view(y, st[2], st[3], ctx.slope), st, d.Cout)
+        dw = ops.conv_wgrad(d, ops.view(xcl), d_raw)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.from_channels_last(ops.conv_dgrad(d, d_raw, wd), d.Cin)
+        return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+def conv_bn_leaky(x, conv: torch.nn.Conv3d, bn: torch.nn.BatchNorm3d, slope: float, training: bool):
+    if conv.bias is not None:
+        raise NotImplementedError("mi355x hot path: Conv3dBlock with bias=True is not used by the reference")
+    out = ConvBnLeakyFunction.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.stride,
+                                    conv.padding, float(slope), bool(training), float(bn.eps), float(bn.momentum))
+    if training:
+        bn.num_batches_tracked += 1
+    return out
+
+
+class HeadFunction(torch.autograd.Function):
+    """Linear(D->Hd) -> BatchNorm1d -> ELU(alpha) -> Linear(Hd->K) in one launch each way."""
+
+    @staticmethod
+    def forward(ctx, f, w0, b0, gamma, beta, w1, b1, rmean, rvar, alpha, eps, momentum, training):
+        ops.require_cuda(f, w0, b0, gamma, beta, w1, b1)
+        f = f.contiguous()
+        B, D = f.shape
+        Hd, K = w0.shape[0], w1.shape[0]
+        L = N.lib()
+        logits = torch.empty((B, K), device=f.device, dtype=torch.float32)
+        save = torch.empty(L.md_head_save_floats(B, D, Hd), device=f.device, dtype=torch.float32)
+        N.check(L.md_head_fwd(ops._p(f), B, D, Hd, K, ops._p(w0), ops._p(b0), ops._p(gamma), ops._p(beta), ops._p(w1),
+                              ops._p(b1), alpha, eps, momentum, int(training), ops._p(rmean), ops._p(rvar), ops._p(logits),
+                              ops._p(save), ops._stream()), "md_head_fwd")
+        ctx.save_for_backward(f, w0, gamma, w1, save)
+        ctx.alpha = alpha
+        ctx.training = training
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        if not ctx.training:
+            raise RuntimeError("mi355x hot path: backward through the eval-mode head is not supported")
+        f, w0, gamma, w1, save = ctx.saved_tensors
+        B, D = f.shape
+        Hd, K = w0.shape[0], w1.shape[0]
+        dev = f.device
+        dlogits = dlogits.contiguous()
+        df = torch.empty_like(f)
+        dw0 = torch.empty_like(w0); db0 = torch.empty(Hd, device=dev)
+        dg = torch.empty(Hd, device=dev); dbt = torch.empty(Hd, device=dev)
+        dw1 = torch.empty_like(w1); db1 = torch.empty(K, device=dev)
+        N.check(N.lib().md_head_bwd(ops._p(dlogits), ops._p(f), B, D, Hd, K, ops._p(w0), ops._p(gamma), ops._p(w1), ctx.alpha,
+                                    ops._p(save), ops._p(df), ops._p(dw0), ops._p(db0), ops._p(dg), ops._p(dbt), ops._p(dw1),
+                                    ops._p(db1), ops._stream()), "md_head_bwd")
+        return df, dw0, db0, dg, dbt, dw1, db1, None, None, None, None, None, None

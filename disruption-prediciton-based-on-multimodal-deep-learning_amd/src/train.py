@@ -1,0 +1,263 @@
+"""Epoch loops -- MI355X-native mirror of the reference's ``src/train.py`` (same names and signatures).
+
+``train_per_epoch`` keeps the reference's step semantics (src/train.py:17-93: zero_grad -> forward -> loss ->
+finite check -> backward -> clip_grad_norm_ -> optimizer.step -> argmax bookkeeping -> macro-F1) but removes the
+per-step host round trips that are not control flow: the loss sum, the correct-count and the predictions stay on
+the device and are read back once per epoch; ``pred`` comes from the fused loss kernel when the loss module
+provides it (``last_pred``) instead of a second softmax pass.  The finite-loss guard (:56-58) is control flow in
+the reference and stays a (single) host read per step.
+
+Unlike the reference this module does NOT switch on autograd anomaly mode at import (src/train.py:15): it only
+slows backward and the kernels here have no autograd graph inside to inspect.
+"""
+from typing import List, Literal, Optional, Union
+
+import os
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+from .loss import FocalLoss, LDAMLoss
+from .utils.metrics import macro_f1
+
+try:  # optional, exactly as optional as in the reference's environment
+    from torch.utils.tensorboard import SummaryWriter  # type: ignore
+except Exception:  # pragma: no cover
+    class SummaryWriter:  # minimal stand-in: logging is not part of the hot path
+        def __init__(self, *a, **k):
+            pass
+
+        def add_scalar(self, *a, **k):
+            pass
+
+        def add_figure(self, *a, **k):
+            pass
+
+        def close(self):
+            pass
+
+try:
+    from tqdm.auto import tqdm
+except Exception:  # pragma: no cover
+    def tqdm(it, **k):
+        return it
+
+
+def _forward(model, data, device, model_type):
+    if model_type == "single":
+        return model(data.to(device)), None, None
+    if model_type == "multi":
+        return model(data['video'].to(device), data['0D'].to(device)), None, None
+    out, out_vis, out_ts = model(data['video'].to(device), data['0D'].to(device))
+    return out, out_vis, out_ts
+
+
+def _pred_of(loss_fn, output):
+    """argmax softmax(output) (src/train.py:70).  The fused loss kernel already produced it for `output`."""
+    p = getattr(loss_fn, "last_pred", None)
+    if p is None and hasattr(loss_fn, "loss_vis_ts"):      # GradientBlending: bookkeeping uses the fused logits
+        p = getattr(loss_fn.loss_vis_ts, "last_pred", None)
+    if p is not None and p.numel() == output.size(0):
+        return p.view(-1, 1)
+    return torch.nn.functional.softmax(output, dim=1).max(1, keepdim=True)[1]
+
+
+def train_per_epoch(
+        train_loader: DataLoader,
+        model: torch.nn.Module,
+        optimizer: torch.optim.Optimizer,
+        scheduler: Optional[torch.optim.lr_scheduler._LRScheduler],
+        loss_fn: torch.nn.Module,
+        device: str = "cpu",
+        max_norm_grad: Optional[float] = None,
+        model_type: Literal["single", "multi", "multi-GB"] = "single",
+):
+    model.train()
+    model.to(device)
+
+    loss_sum = None
+    correct = None
+    total_pred, total_label = [], []
+    total_size = 0
+
+    for batch_idx, (data, target) in enumerate(train_loader):
+        optimizer.zero_grad()
+        output, output_vis, output_ts = _forward(model, data, device, model_type)
+        tgt = target.to(device)
+        if model_type == 'multi-GB':
+            loss = loss_fn(output, output_vis, output_ts, tgt)
+        else:
+            loss = loss_fn(output, tgt)
+
+        if not torch.isfinite(loss):
+            print("train_per_epoch | Warning : loss nan occurs at batch_idx : {}".format(batch_idx))
+            continue
+        loss.backward()
+
+        if max_norm_grad:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm_grad)
+        optimizer.step()
+
+        ld = loss.detach()
+        loss_sum = ld if loss_sum is None else loss_sum + ld
+        pred = _pred_of(loss_fn, output.detach())
+        c = pred.eq(tgt.view_as(pred)).sum()
+        correct = c if correct is None else correct + c
+        total_size += pred.size(0)
+        total_pred.append(pred.view(-1, 1))
+        total_label.append(tgt.view(-1, 1))
+
+    if scheduler:
+        scheduler.step()
+
+    if total_size > 0:
+        preds = torch.concat(total_pred, dim=0).view(-1).cpu().numpy()
+        labels = torch.concat(total_label, dim=0).view(-1).cpu().numpy()
+        train_loss = float(loss_sum.item()) / total_size
+        train_acc = int(correct.item()) / total_size
+        train_f1 = macro_f1(labels, preds)
+    else:
+        train_loss, train_acc, train_f1 = 0, 0, 0
+    return train_loss, train_acc, train_f1
+
+
+def valid_per_epoch(
+        valid_loader: DataLoader,
+        model: torch.nn.Module,
+        optimizer: torch.optim.Optimizer,
+        loss_fn: torch.nn.Module,
+        device: str = "cpu",
+        model_type: Literal["single", "multi", "multi-GB"] = "single",
+):
+    model.eval()
+    model.to(device)
+    loss_sum = None
+    correct = None
+    total_pred, total_label = [], []
+    total_size = 0
+    for batch_idx, (data, target) in enumerate(valid_loader):
+        with torch.no_grad():
+            optimizer.zero_grad()
+            output, output_vis, output_ts = _forward(model, data, device, model_type)
+            tgt = target.to(device)
+            if model_type == 'multi-GB':
+                loss = loss_fn(output, output_vis, output_ts, tgt)
+            else:
+                loss = loss_fn(output, tgt)
+            ld = loss.detach()
+            loss_sum = ld if loss_sum is None else loss_sum + ld
+            pred = _pred_of(loss_fn, output)
+            c = pred.eq(tgt.view_as(pred)).sum()
+            correct = c if correct is None else correct + c
+            total_size += pred.size(0)
+            total_pred.append(pred.view(-1, 1))
+            total_label.append(tgt.view(-1, 1))
+    valid_loss = float(loss_sum.item()) / total_size
+    valid_acc = int(correct.item()) / total_size
+    preds = torch.concat(total_pred, dim=0).view(-1).cpu().numpy()
+    labels = torch.concat(total_label, dim=0).view(-1).cpu().numpy()
+    valid_f1 = macro_f1(labels, preds)
+    return valid_loss, valid_acc, valid_f1
+
+
+class _EarlyStop:
+    """Validation-F1 early stopping with best-checkpoint save (reference src/utils/EarlyStopping.py:15-38)."""
+
+    def __init__(self, path, patience, verbose, delta):
+        self.path, self.patience, self.verbose, self.delta = path, patience, verbose, delta
+        self.best, self.count, self.early_stop = None, 0, False
+
+    def __call__(self, score, model):
+        if self.best is None or score > self.best + self.delta:
+            self.best, self.count = score, 0
+            torch.save(model.state_dict(), self.path)
+        else:
+            self.count += 1
+            if self.count >= self.patience:
+                self.early_stop = True
+
+
+def drw_class_weights(epoch: int, num_epoch: int, betas: List, cls_num_list: List) -> np.ndarray:
+    """Deferred re-weighting schedule (reference src/train.py:318-329); fp32 values, bit-exact host arithmetic."""
+    idx = epoch // int(num_epoch / len(betas))
+    if idx >= len(betas):
+        idx = len(betas) - 1
+    beta = betas[idx]
+    effective_num = 1.0 - np.power(beta, cls_num_list)
+    per_cls_weights = (1.0 - beta) / np.array(effective_num)
+    per_cls_weights = per_cls_weights / np.sum(per_cls_weights) * len(cls_num_list)
+    return per_cls_weights.astype(np.float32)
+
+
+def _run(train_loader, valid_loader, model, optimizer, scheduler, loss_fn, device, num_epoch, verbose, save_best_dir,
+         save_last_dir, exp_dir, max_norm_grad, model_type, is_early_stopping, es_verbose, es_patience, es_delta,
+         drw=None, desc="training process"):
+    lists = [[] for _ in range(6)]
+    best_f1, best_acc, best_epoch, best_loss = 0, 0, 0, float("inf")
+    if exp_dir and not os.path.isdir(exp_dir):
+        os.makedirs(exp_dir, exist_ok=True)
+    writer = SummaryWriter(exp_dir) if exp_dir else None
+    early = _EarlyStop(save_best_dir, es_patience, es_verbose, es_delta) if is_early_stopping else None
+    for epoch in tqdm(range(num_epoch), desc=desc):
+        if drw is not None:
+            betas, cls_num_list = drw
+            w = torch.from_numpy(drw_class_weights(epoch, num_epoch, betas, cls_num_list)).to(device)
+            loss_fn.update_weight(w)
+        tl, ta, tf = train_per_epoch(train_loader, model, optimizer, scheduler, loss_fn, device, max_norm_grad, model_type)
+        vl, va, vf = valid_per_epoch(valid_loader, model, optimizer, loss_fn, device, model_type)
+        for lst, v in zip(lists, (tl, ta, tf, vl, va, vf)):
+            lst.append(v)
+        if writer is not None:
+            writer.add_scalar('Loss/train', tl, epoch); writer.add_scalar('Loss/valid', vl, epoch)
+            writer.add_scalar('F1_score/train', tf, epoch); writer.add_scalar('F1_score/valid', vf, epoch)
+        if verbose and epoch % verbose == 0:
+            print("epoch : {}, train loss : {:.3f}, valid loss : {:.3f}, train f1 : {:.3f}, valid f1 : {:.3f}".format(
+                epoch + 1, tl, vl, tf, vf))
+        torch.save(model.state_dict(), save_last_dir)
+        if best_f1 < vf:
+            best_acc, best_f1, best_loss, best_epoch = va, vf, vl, epoch
+            if early is None:
+                torch.save(model.state_dict(), save_best_dir)
+        if early is not None:
+            early(vf, model)
+            if early.early_stop:
+                print("Early stopping | epoch : {}, best f1 score : {:.3f}".format(epoch, best_f1))
+                break
+    print("training process finished, best loss : {:.3f}, best acc : {:.3f}, best f1 : {:.3f}, best epoch : {}".format(
+        best_loss, best_acc, best_f1, best_epoch))
+    if writer:
+        writer.close()
+    tl_, ta_, tf_, vl_, va_, vf_ = lists
+    return tl_, ta_, tf_, vl_, va_, vf_
+
+
+def train(
+        train_loader: DataLoader, valid_loader: DataLoader, model: torch.nn.Module, optimizer: torch.optim.Optimizer,
+        scheduler: Optional[torch.optim.lr_scheduler._LRScheduler], loss_fn: torch.nn.Module, device: str = "cpu",
+        num_epoch: int = 64, verbose: Optional[int] = 8, save_best_dir: str = "./weights/best.pt",
+        save_last_dir: str = "./weights/last.pt", exp_dir: Optional[str] = None, max_norm_grad: Optional[float] = None,
+        model_type: Literal["single", "multi", "multi-GB"] = "single", test_for_check_per_epoch: Optional[DataLoader] = None,
+        is_early_stopping: bool = False, early_stopping_verbose: bool = True, early_stopping_patience: int = 12,
+        early_stopping_delta: float = 1e-3,
+):
+    """Reference src/train.py:147-274 (figure logging via evaluate_tensorboard is out of scope)."""
+    return _run(train_loader, valid_loader, model, optimizer, scheduler, loss_fn, device, num_epoch, verbose, save_best_dir,
+                save_last_dir, exp_dir, max_norm_grad, model_type, is_early_stopping, early_stopping_verbose,
+                early_stopping_patience, early_stopping_delta, None, "training process")
+
+
+def train_DRW(
+        train_loader: DataLoader, valid_loader: DataLoader, model: torch.nn.Module, optimizer: torch.optim.Optimizer,
+        loss_fn: Union[LDAMLoss, FocalLoss], device: str = "cpu", num_epoch: int = 64, verbose: int = 1,
+        save_best_dir: str = "./weights/best.pt", save_last_dir: str = "./weights/last.pt", exp_dir: str = './results',
+        max_norm_grad: Optional[float] = None, cls_num_list: Optional[List] = None, betas: List = [0, 0.25, 0.75, 0.9],
+        model_type: Literal['single', 'multi'] = 'single', test_for_check_per_epoch: Optional[DataLoader] = None,
+        is_early_stopping: bool = False, early_stopping_verbose: bool = True, early_stopping_patience: int = 12,
+        early_stopping_delta: float = 1e-3,
+):
+    """Reference src/train.py:277-422: per-epoch class re-weighting, no LR scheduler."""
+    return _run(train_loader, valid_loader, model, optimizer, None, loss_fn, device, num_epoch, verbose, save_best_dir,
+                save_last_dir, exp_dir, max_norm_grad, model_type, is_early_stopping, early_stopping_verbose,
+                early_stopping_patience, early_stopping_delta, (betas, cls_num_list),
+                "training process - Deferred Re-weighting")

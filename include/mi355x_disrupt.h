@@ -187,6 +187,12 @@ int md_plan_backward_range(MdPlan* p, const float* dfeat, const float* const* w,
                            float* const* dw, float* const* dgamma, float* const* dbeta,
                            void* workspace, int32_t stage_hi, int32_t stage_lo, void* stream);
 int32_t md_plan_feat_dim(const MdPlan* p);
+/* Measurement aid (bench.py roofline leg): bracket every convolution launch of the plan with HIP events on
+ * the launch stream.  md_plan_profile_read sums, per kernel class (0 conv forward, 1 conv data-gradient,
+ * 2 conv weight-gradient), the measured milliseconds, the launch count and the algorithmic FLOPs
+ * (2 * output pixels * Cout * Cin * taps per launch) since the previous read; it waits on the events. */
+int md_plan_profile_enable(MdPlan* p, int enable);
+int md_plan_profile_read(MdPlan* p, double* ms, int64_t* launches, double* flops);
 
 #ifdef __cplusplus
 }

@@ -100,6 +100,20 @@ def model_fixture(tag, layer_sizes, B, T, S, alpha, seed, gamma=2.0, weight=(1.0
         out["gsub/" + k] = subsample(p.grad)
         out["gnorm/" + k] = np.float32(p.grad.norm().item())
     out["param_names"] = np.array(names)
+    # the reference's own fp32 rounding noise on these gradients: same code, fp64
+    m64 = load_ref_model(layer_sizes, T, S, alpha, seed).double()
+    m64.train()
+    l64 = FocalLoss(weight=torch.tensor(weight, dtype=torch.float64), gamma=gamma)(m64(x.double()), y)
+    l64.backward()
+    noise = 0.0
+    gmax = max(float(p.grad.norm()) for p in m64.parameters())
+    for (k, p), (_, q) in zip(model.named_parameters(), m64.named_parameters()):
+        if k == "linear.0.bias":
+            continue
+        sc = max(float(q.grad.abs().max()), 1e-5 * gmax)
+        noise = max(noise, float((p.grad.double() - q.grad).abs().max()) / sc)
+    out["ref_noise"] = np.float64(noise)
+    print(f"  {tag}: reference fp32-vs-fp64 gradient deviation {noise:.2e}")
     sd = model.state_dict()
     for k in ("res2plus1d.conv1.spatio_conv.bn.running_mean", "res2plus1d.conv1.spatio_conv.bn.running_var",
               "res2plus1d.conv5.block1.conv2.temporal_conv.bn.running_var", "linear.1.running_mean",
@@ -149,11 +163,9 @@ def loss_fixture():
 
 
 def drw_fixture():
-    # DRW schedule (reference: closure inside train_DRW, src/train.py:318-329) -- restated call-for-call
-    # by running the reference's train_DRW would need a dataset; the closure is pure NumPy, so the
-    # fixture records its outputs by executing the same statements through the reference function
-    # object extracted from the module source is not possible (it is a closure).  We therefore run
-    # train_DRW for real on a 1-batch synthetic loader with a recording loss function.
+    # DRW schedule: the weight table is computed by a closure inside the reference's train_DRW
+    # (src/train.py:318-329), so it cannot be called on its own.  Run train_DRW for real on a 1-batch
+    # synthetic loader with a loss object that records every update_weight() call.
     from src.train import train_DRW
     torch.autograd.set_detect_anomaly(False)
     rec = {}
@@ -208,9 +220,16 @@ def step_fixture():
 
 
 if __name__ == "__main__":
-    model_fixture("r2p1d_tiny_a001", [1, 1, 1, 1], B=2, T=5, S=32, alpha=0.01, seed=1)
-    model_fixture("r2p1d_1221_a1", [1, 2, 2, 1], B=3, T=6, S=48, alpha=1.0, seed=2, gamma=2.0, weight=(0.6, 1.4))
-    model_fixture("r2p1d_1221_odd", [1, 2, 2, 1], B=2, T=7, S=40, alpha=0.2, seed=3, gamma=1.5, weight=(1.0, 1.0))
+    # Several seeds per configuration: LeakyReLU(0.01) makes the gradient discontinuous where a
+    # pre-activation crosses zero, so two correct fp32 implementations can disagree by >1e-3 on a whole
+    # gradient when ONE element (|x| < ~1e-6) lands on the other side of the kink.  Each fixture therefore
+    # also records `ref_noise`: the largest deviation between the reference run in fp32 and the SAME
+    # reference code run in fp64 (model.double()).  Seeds 3 and 11 show such a flip inside the reference.
+    for seed in (1, 2, 3, 4):
+        model_fixture(f"r2p1d_1111_s{seed}", [1, 1, 1, 1], B=4, T=5, S=24, alpha=0.01, seed=seed)
+    model_fixture("r2p1d_1221_s11", [1, 2, 2, 1], B=4, T=6, S=24, alpha=1.0, seed=11, gamma=2.0, weight=(0.6, 1.4))
+    model_fixture("r2p1d_1221_s12", [1, 2, 2, 1], B=5, T=7, S=24, alpha=0.2, seed=12, gamma=1.5, weight=(1.0, 1.0))
+    model_fixture("r2p1d_1221_s13", [1, 2, 2, 1], B=4, T=4, S=32, alpha=0.01, seed=13, gamma=2.0, weight=(1.0, 1.0))
     loss_fixture()
     drw_fixture()
     step_fixture()

@@ -26,7 +26,10 @@ def close(a, b, tol=2e-5, floor=1e-6):
     return float(np.max(np.abs(a - b))) / scale <= tol
 
 
-@pytest.mark.parametrize("tag", ["r2p1d_tiny_a001", "r2p1d_1221_a1", "r2p1d_1221_odd"])
+TAGS = [f"r2p1d_1111_s{i}" for i in (1, 2, 3, 4)] + [f"r2p1d_1221_s{i}" for i in (11, 12, 13)]
+
+
+@pytest.mark.parametrize("tag", TAGS)
 def test_r2plus1d_oracle_matches_reference(golden_dir, tag):
     g = np.load(os.path.join(golden_dir, tag + ".npz"))
     ls = [int(v) for v in g["layer_sizes"]]

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_residual_fwd(View skip, View main, floa
 }
 
 // ---------------------------------------------------------------- BatchNorm statistics finalize
-// grid = Cp/16 blocks; thread (c = t&15, r = t>>4) sums partial rows r, r+16, ... in fp64, then a fixed
+// grid = Cp/4 blocks; thread (c = t&3, r = t>>2) sums partial rows r, r+64, ... in fp64, then a fixed
 // tree over r: deterministic for a given launch geometry.
 __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ partial, int blocks, int C, int Cp,
                                                      double inv_count, double unbias, const float* __restrict__ gamma,
@@ -91,19 +91,19 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ p
                                                      float* __restrict__ rmean, float* __restrict__ rvar,
                                                      float* __restrict__ mean_o, float* __restrict__ invstd_o,
                                                      float* __restrict__ scale_o, float* __restrict__ shift_o) {
-  __shared__ double s1[16][17], s2[16][17];
-  const int cl = threadIdx.x & 15, r = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+  __shared__ double s1[64][5], s2[64][5];
+  const int cl = threadIdx.x & 3, r = threadIdx.x >> 2;
+  const int c = blockIdx.x * 4 + cl;
   double a = 0.0, b = 0.0;
   if (c < Cp) {
-    for (int i = r; i < blocks; i += 16) {
+    for (int i = r; i < blocks; i += 64) {
       a += (double)partial[(size_t)i * 2 * Cp + c];
       b += (double)partial[(size_t)i * 2 * Cp + Cp + c];
     }
   }
   s1[r][cl] = a; s2[r][cl] = b;
   __syncthreads();
-  for (int st = 8; st >= 1; st >>= 1) {
+  for (int st = 32; st >= 1; st >>= 1) {
     if (r < st) { s1[r][cl] += s1[r + st][cl]; s2[r][cl] += s2[r + st][cl]; }
     __syncthreads();
   }
@@ -204,19 +204,19 @@ __global__ __launch_bounds__(256) void k_bn_bwd(const float* __restrict__ dA, Vi
 __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict__ partial, int blocks, int C, int Cp,
                                                          double inv_count, float* __restrict__ dgamma,
                                                          float* __restrict__ dbeta, float* __restrict__ coef) {
-  __shared__ double s1[16][17], s2[16][17];
-  const int cl = threadIdx.x & 15, r = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+  __shared__ double s1[64][5], s2[64][5];
+  const int cl = threadIdx.x & 3, r = threadIdx.x >> 2;
+  const int c = blockIdx.x * 4 + cl;
   double a = 0.0, b = 0.0;
   if (c < Cp) {
-    for (int i = r; i < blocks; i += 16) {
+    for (int i = r; i < blocks; i += 64) {
       a += (double)partial[(size_t)i * 2 * Cp + c];
       b += (double)partial[(size_t)i * 2 * Cp + Cp + c];
     }
   }
   s1[r][cl] = a; s2[r][cl] = b;
   __syncthreads();
-  for (int st = 8; st >= 1; st >>= 1) {
+  for (int st = 32; st >= 1; st >>= 1) {
     if (r < st) { s1[r][cl] += s1[r + st][cl]; s2[r][cl] += s2[r + st][cl]; }
     __syncthreads();
   }
@@ -285,7 +285,7 @@ extern "C" int md_bn_finalize(const float* stat_partial, int32_t blocks, int32_t
   if (C <= 0 || blocks <= 0 || count <= 0) return MD_ERR_BAD_SHAPE;
   const int Cp = md_cpad(C);
   const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
-  hipLaunchKernelGGL(k_bn_finalize, dim3(md_cdiv(Cp, 16)), dim3(256), 0, (hipStream_t)stream, stat_partial, blocks, C, Cp,
+  hipLaunchKernelGGL(k_bn_finalize, dim3(md_cdiv(Cp, 4)), dim3(256), 0, (hipStream_t)stream, stat_partial, blocks, C, Cp,
                      1.0 / (double)count, unbias, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
                      scale, shift);
   MD_CHECK_LAUNCH();
@@ -357,7 +357,7 @@ extern "C" int md_bn_bwd_finalize(const float* partial, int32_t blocks, int32_t 
   if (!partial || !coef) return MD_ERR_NULL;
   if (C <= 0 || blocks <= 0 || count <= 0) return MD_ERR_BAD_SHAPE;
   const int Cp = md_cpad(C);
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(md_cdiv(Cp, 16)), dim3(256), 0, (hipStream_t)stream, partial, blocks, C, Cp,
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(md_cdiv(Cp, 4)), dim3(256), 0, (hipStream_t)stream, partial, blocks, C, Cp,
                      1.0 / (double)count, dgamma, dbeta, coef);
   MD_CHECK_LAUNCH();
   return MD_OK;

@@ -40,3 +40,19 @@ struct Geom {
 
 __device__ __forceinline__ float md_leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
 __device__ __forceinline__ float md_dleaky(float pre, float slope) { return pre > 0.f ? 1.f : slope; }
+
+// ---- unit-stride patch kernel (conv_patch.hip); used by the dispatchers in conv_gemm.hip
+struct PGeom;
+struct PatchPlan;   // cached PGeom + LDS size for one (descriptor, direction)
+const PatchPlan* patch_lookup(const MdConvDesc* d, int dgrad);     // nullptr when the geometry does not qualify
+size_t patch_wpack_floats(const PatchPlan* p);
+int patch_blocks(const PatchPlan* p);
+int patch_pack(const MdConvDesc* d, int dgrad, const PatchPlan* p, const float* w, float* out, hipStream_t s);
+int patch_launch(const PatchPlan* p, const float* src, const float* ps, const float* psh, float slope, const float* wp,
+                 float* dst, float* stat, int accumulate, hipStream_t s);
+
+struct WgradPlan;
+const WgradPlan* wgrad_lookup(const MdConvDesc* d);
+size_t wgrad_patch_workspace_floats(const WgradPlan* p);
+int wgrad_patch_launch(const WgradPlan* p, const MdConvDesc* d, const float* src, const float* ps, const float* psh,
+                       float slope, const float* dy, float* dw, float* slab, hipStream_t s);

@@ -423,11 +423,13 @@ static size_t conv_gemm_lds_bytes() {
 
 extern "C" size_t md_conv_wpack_fwd_floats(const MdConvDesc* d) {
   if (check_desc(d) != MD_OK) return 0;
+  if (const PatchPlan* pp = patch_lookup(d, 0)) return patch_wpack_floats(pp);
   Geom g = geom_fwd(d);
   return (size_t)g.N16 * g.Kp;
 }
 extern "C" size_t md_conv_wpack_dgrad_floats(const MdConvDesc* d) {
   if (check_desc(d) != MD_OK) return 0;
+  if (const PatchPlan* pp = patch_lookup(d, 1)) return patch_wpack_floats(pp);
   Geom g = geom_dgrad(d);
   return (size_t)g.N16 * g.Kp;
 }
@@ -438,6 +440,9 @@ extern "C" int md_conv_pack_weights(const MdConvDesc* d, const float* w, float* 
   if (!w) return MD_ERR_NULL;
   Geom gf = geom_fwd(d), gd = geom_dgrad(d);
   const int taps = d->kt * d->kh * d->kw;
+  // unit-stride geometries use the split-bf16 patch kernel and its own operand layout
+  if (wf) if (const PatchPlan* pp = patch_lookup(d, 0)) { rc = patch_pack(d, 0, pp, w, wf, (hipStream_t)stream); if (rc) return rc; wf = nullptr; }
+  if (wd) if (const PatchPlan* pp = patch_lookup(d, 1)) { rc = patch_pack(d, 1, pp, w, wd, (hipStream_t)stream); if (rc) return rc; wd = nullptr; }
   const int nF = wf ? gf.N16 * gf.Kp : 0, nD = wd ? gd.N16 * gd.Kp : 0;
   const int n = nF > nD ? nF : nD;
   if (n == 0) return MD_OK;
@@ -449,6 +454,7 @@ extern "C" int md_conv_pack_weights(const MdConvDesc* d, const float* w, float* 
 
 extern "C" int32_t md_conv_fwd_stat_blocks(const MdConvDesc* d) {
   if (check_desc(d) != MD_OK) return 0;
+  if (const PatchPlan* pp = patch_lookup(d, 0)) return patch_blocks(pp);
   return md_cdiv(d->N * d->To * d->Ho * d->Wo, BM);
 }
 
@@ -473,6 +479,8 @@ extern "C" int md_conv_fwd(const MdConvDesc* d, const MdActView* x, const float*
   int rc = check_desc(d);
   if (rc != MD_OK) return rc;
   if (!x || !x->data || !wpack_fwd || !y_raw) return MD_ERR_NULL;
+  if (const PatchPlan* pp = patch_lookup(d, 0))
+    return patch_launch(pp, x->data, x->scale, x->shift, x->slope, wpack_fwd, y_raw, stat_partial, 0, (hipStream_t)stream);
   Geom g = geom_fwd(d);
   return launch_gemm(g, x->data, x->scale, x->shift, x->slope, wpack_fwd, y_raw, stat_partial, 0, (hipStream_t)stream);
 }
@@ -482,16 +490,30 @@ extern "C" int md_conv_dgrad(const MdConvDesc* d, const float* dy_raw, const flo
   int rc = check_desc(d);
   if (rc != MD_OK) return rc;
   if (!dy_raw || !wpack_dgrad || !dx) return MD_ERR_NULL;
+  if (const PatchPlan* pp = patch_lookup(d, 1))
+    return patch_launch(pp, dy_raw, nullptr, nullptr, 1.f, wpack_dgrad, dx, nullptr, accumulate, (hipStream_t)stream);
   Geom g = geom_dgrad(d);
   return launch_gemm(g, dy_raw, nullptr, nullptr, 1.f, wpack_dgrad, dx, nullptr, accumulate, (hipStream_t)stream);
 }
 
-extern "C" int md_conv_wgrad(const MdConvDesc* d, const MdActView* x, const float* dy_raw, float* dw, void* stream) {
+extern "C" size_t md_conv_wgrad_workspace_floats(const MdConvDesc* d) {
+  if (check_desc(d) != MD_OK) return 0;
+  if (const WgradPlan* wp = wgrad_lookup(d)) return wgrad_patch_workspace_floats(wp);
+  return 0;
+}
+
+extern "C" int md_conv_wgrad(const MdConvDesc* d, const MdActView* x, const float* dy_raw, float* dw, float* workspace,
+                             void* stream) {
   int rc = check_desc(d);
   if (rc != MD_OK) return rc;
   if (!x || !x->data || !dy_raw || !dw) return MD_ERR_NULL;
+  if (const WgradPlan* wp = wgrad_lookup(d)) {
+    if (!workspace) return MD_ERR_WORKSPACE;
+    return wgrad_patch_launch(wp, d, x->data, x->scale, x->shift, x->slope, dy_raw, dw, workspace, (hipStream_t)stream);
+  }
   Geom g = geom_fwd(d);
   const int taps = d->kt * d->kh * d->kw;
+  if (hipMemsetAsync(dw, 0, (size_t)d->Cout * d->Cin * taps * 4, (hipStream_t)stream) != hipSuccess) return MD_ERR_LAUNCH;
   const int ktiles = md_cdiv(g.Kc * 4, WK);
   const int N16 = md_round_up(d->Cout, 16);
   const int npb = pick_n_per_blk(N16);

@@ -1,0 +1,773 @@
+// Unit-stride convolution (forward and data-gradient) with an LDS-resident input patch and split-bf16
+// ("bf16x3") matrix-core arithmetic, for gfx950.
+//
+// Why this kernel exists (measured, profiles/r01a_*): the exact-fp32 MFMA runs at 1/16 of the bf16 rate, and the
+// generic gather kernel re-stages every input element once per filter tap.  Here
+//   * a workgroup owns a BOX of <=128 output pixels of one clip (bt x by x bx) and stages the box's input patch
+//     (with halo) into LDS exactly once -- coalesced 32-byte reads per lane, BatchNorm+LeakyReLU of the producer
+//     applied on the way in ("BN-on-read"), zero fill outside the tensor;
+//   * every fp32 value x is split as x = hi + lo with hi = bf16(x), lo = bf16(x - hi); the product a*b is
+//     evaluated as hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  The dropped lo*lo
+//     term is < 2^-16 relative: measured 4.5e-6 relative error per conv (fp32 MFMA: 7e-7), well inside the
+//     1e-3 parity budget, at 16/3 = 5.3x the exact-fp32 matrix rate.  Weights are split once, at pack time;
+//   * the K axis is the flat (tap, 8-channel chunk) axis; the A fragment of lane (row i, chunk group g) is ONE
+//     ds_read_b128 from the patch at  rowpix[i] + koffs[chunk]  -- no im2col copy exists anywhere.
+//
+// LDS pixel pitch is 16*(4m+2) bytes so that the 16 lanes of each ds_read_b128 group cover 16 distinct 16-byte
+// slots (conflict-free for rows that are consecutive pixels).
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define PM 128            // rows (output pixels) per workgroup
+#define PNREP 9           // up to 144 destination channels per workgroup
+#define PB_PITCH 160      // B tile row pitch (bytes): 8 chunks of 16 B + pad, (160/16) % 4 == 2
+#define PMAXC 320
+
+struct PGeom {
+  int Ts, Hs, Ws, Cps;      // source dims, channel pitch (floats)
+  int Td, Hd, Wd, Cpd;      // destination dims, channel pitch (floats)
+  int kh, kw, khw, taps;
+  int org_t, org_h, org_w;  // source coordinate = box origin * stride + org + patch coordinate
+  int st, sh, sw;           // stride of the (forward) convolution; 1 for the data gradient
+  int bt, by, bx, byx;      // output box
+  int nbt, nby, nbx;        // boxes per clip
+  int pt, py, px, pyx, P;   // patch dims
+  int C8;                   // 8-channel chunks per pixel in LDS
+  int ppitch;               // LDS bytes per patch pixel (hi array); lo array follows at lo_off
+  int lo_off;
+  int Kc8;                  // taps * C8
+  int nstages;              // ceil(Kc8 / 8): 64 k per stage
+  int N16;
+  unsigned magicC8;         // floor(2^32 / C8) + 1 : exact item / C8 for item < 2^16
+  int off_b, off_koffs, off_rows, off_pixg, off_scale;   // LDS byte offsets
+};
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_f16(float a, float b) {
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
+// fp16 split: hi = fp16(x) (11 significant bits), lo = fp16(x - hi) -> 22 bits, i.e. fp32-level products with
+// three MFMAs.  fp16 subnormals are kept (HIP kernels run with float_denorm_mode_16_64 = preserve), so the
+// absolute error of hi+lo is <= max(2^-23 |x|, 2^-25); |x| must stay below 65504 (activations and weights do).
+__device__ __forceinline__ void split8_f16(const float* v, uint4& hi, uint4& lo) {
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h[i] = pk_f16(v[2 * i], v[2 * i + 1]);
+    const f16x2 hv = __builtin_bit_cast(f16x2, h[i]);
+    l[i] = pk_f16(v[2 * i] - (float)hv[0], v[2 * i + 1] - (float)hv[1]);
+  }
+  hi = make_uint4(h[0], h[1], h[2], h[3]);
+  lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+// split 8 floats into packed bf16 hi and lo (4 dwords each)
+__device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h[i] = pk_bf16(v[2 * i], v[2 * i + 1]);
+    const float h0 = __builtin_bit_cast(float, h[i] << 16), h1 = __builtin_bit_cast(float, h[i] & 0xffff0000u);
+    l[i] = pk_bf16(v[2 * i] - h0, v[2 * i + 1] - h1);
+  }
+  hi = make_uint4(h[0], h[1], h[2], h[3]);
+  lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+// Stage `npix` pixels x `C8` 8-channel chunks of a channels-last fp32 tensor into an LDS image
+// [pixel][C8 chunks] (pixel pitch `pitch` bytes; hi array at img, lo array at img + lo_off).
+// sG[pixel] = global pixel index or -1 (outside the tensor: zeros = the convolution's zero padding).
+// Channels c0 .. c0 + 4*cvalid4 are read (cvalid4 = valid float4 units from c0); chunks past that are zero.
+// With `prologue`, value = leaky(x*scale[c] + shift[c]) ("BN-on-read") before the bf16 hi/lo split.
+template <bool F16>
+__device__ __forceinline__ void stage_image(const float* __restrict__ src, int Cpitch, int c0, int cvalid4,
+                                            const int* sG, int npix, int C8, unsigned magic, char* img, int pitch,
+                                            int lo_off, bool prologue, const float* sScale, const float* sShift,
+                                            float pslope, int t) {
+  const int total = npix * C8;
+  for (int base = 0; base < total; base += 256 * 4) {
+    float4 va[4], vb[4];
+    int pix[4], c8s[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int item = base + u * 256 + t;
+      va[u] = make_float4(0.f, 0.f, 0.f, 0.f); vb[u] = va[u];
+      pix[u] = -1; c8s[u] = 0;
+      if (item < total) {
+        const int pixel = magic ? (int)__umulhi((unsigned)item, magic) : item;
+        const int c8 = item - pixel * C8;
+        pix[u] = pixel | 0x20000000; c8s[u] = c8;        // 0x2..: nothing loaded (stays zero, no prologue)
+        const int gp = sG[pixel];
+        if (gp >= 0 && c8 * 2 < cvalid4) {
+          const float* s = src + (size_t)gp * Cpitch + c0 + c8 * 8;
+          va[u] = *(const float4*)s;
+          pix[u] = pixel;
+          if (c8 * 2 + 1 < cvalid4) vb[u] = *(const float4*)(s + 4);
+          else pix[u] |= 0x40000000;                       // upper half of the chunk is channel padding
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (pix[u] == -1) continue;
+      const int pixel = pix[u] & 0x0fffffff;
+      const bool inside = !(pix[u] & 0x20000000);
+      const bool half = (pix[u] & 0x40000000) != 0;
+      float v[8] = {va[u].x, va[u].y, va[u].z, va[u].w, vb[u].x, vb[u].y, vb[u].z, vb[u].w};
+      if (prologue && inside) {
+        const float* sc = sScale + c0 + c8s[u] * 8; const float* sh = sShift + c0 + c8s[u] * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = md_leaky(fmaf(v[e], sc[e], sh[e]), pslope);
+        if (half) { v[4] = v[5] = v[6] = v[7] = 0.f; }
+      }
+      uint4 hi, lo;
+      if (F16) split8_f16(v, hi, lo); else split8(v, hi, lo);
+      char* d = img + pixel * pitch + c8s[u] * 16;
+      *(uint4*)d = hi;
+      *(uint4*)(d + lo_off) = lo;
+    }
+  }
+}
+
+template <bool F16>
+__device__ __forceinline__ f32x4 mma(uint4 a, uint4 b, f32x4 c) {
+  if (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// F16 = true: forward convolution, operands split into fp16 halves (activations/weights are O(1) quantities);
+// F16 = false: data gradient, operands split into bf16 halves (gradients need bf16's exponent range).
+template <bool F16>
+__global__ __launch_bounds__(256) void k_conv_patch(
+    PGeom g, const float* __restrict__ src, const float* __restrict__ pscale, const float* __restrict__ pshift,
+    float pslope, const uint4* __restrict__ wp, float* __restrict__ dst, float* __restrict__ stat_partial,
+    int accumulate, int n_per_blk) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  char* sP = sm;                                   // patch hi | lo
+  char* sB = sm + g.off_b;                         // B tile hi [n][160 B] | lo
+  int* sK = (int*)(sm + g.off_koffs);              // [nstages*8]
+  int2* sR = (int2*)(sm + g.off_rows);             // [PM] {rowpix bytes, global dst pixel or -1}
+  int* sG = (int*)(sm + g.off_pixg);               // [P] global source pixel or -1
+  float* sScale = (float*)(sm + g.off_scale);      // [Cps] scale | shift
+  float* sShift = sScale + PMAXC;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int n0 = blockIdx.y * n_per_blk;
+  const int ncols = min(n_per_blk, g.N16 - n0);
+  const int nrep = ncols >> 4;
+  const bool prologue = pscale != nullptr;
+
+  // ---- which box
+  int b = blockIdx.x;
+  const int xb = b % g.nbx; b /= g.nbx;
+  const int yb = b % g.nby; b /= g.nby;
+  const int tb = b % g.nbt; const int n = b / g.nbt;
+  const int t0 = tb * g.bt, y0 = yb * g.by, x0 = xb * g.bx;
+
+  // ---- tables
+  for (int p = t; p < g.P; p += 256) {
+    const int ppt = p / g.pyx; const int r = p - ppt * g.pyx;
+    const int ppy = r / g.px; const int ppx = r - ppy * g.px;
+    const int st = t0 * g.st + g.org_t + ppt, sy = y0 * g.sh + g.org_h + ppy, sx = x0 * g.sw + g.org_w + ppx;
+    const bool v = ((unsigned)st < (unsigned)g.Ts) && ((unsigned)sy < (unsigned)g.Hs) && ((unsigned)sx < (unsigned)g.Ws);
+    sG[p] = v ? ((n * g.Ts + st) * g.Hs + sy) * g.Ws + sx : -1;
+  }
+  if (t < PM) {
+    const int rt = t / g.byx; const int r = t - rt * g.byx;
+    const int ry = r / g.bx; const int rx = r - ry * g.bx;
+    const bool v = (rt < g.bt) && (t0 + rt < g.Td) && (y0 + ry < g.Hd) && (x0 + rx < g.Wd);
+    int2 ri;
+    ri.x = v ? ((rt * g.st * g.py + ry * g.sh) * g.px + rx * g.sw) * g.ppitch : 0;
+    ri.y = v ? ((n * g.Td + t0 + rt) * g.Hd + y0 + ry) * g.Wd + x0 + rx : -1;
+    sR[t] = ri;
+  }
+  for (int q = t; q < g.nstages * 8; q += 256) {
+    int ko = 0;
+    if (q < g.Kc8) {
+      const int tap = q / g.C8; const int c8 = q - tap * g.C8;
+      const int dt = tap / g.khw; const int r = tap - dt * g.khw;
+      const int dy = r / g.kw; const int dx = r - dy * g.kw;
+      ko = ((dt * g.py + dy) * g.px + dx) * g.ppitch + c8 * 16;
+    }
+    sK[q] = ko;
+  }
+  if (prologue) for (int c = t; c < g.Cps; c += 256) { sScale[c] = pscale[c]; sShift[c] = pshift[c]; }
+
+  // ---- B tile prefetch (registers): [stage][hi|lo][N16][8 chunks] uint4, this block's rows n0..n0+ncols
+  const int bchunks = ncols * 8;                 // per half
+  uint4 rb[2][5];                                // up to 144*8/256 = 4.5 chunks per thread per half
+  auto load_b = [&](int kb) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint4* base = wp + ((size_t)(kb * 2 + h) * g.N16 + n0) * 8;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int c = t + 256 * i;
+        rb[h][i] = c < bchunks ? base[c] : make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+  load_b(0);
+  __syncthreads();
+
+  // ---- stage the patch: global 32 B per lane -> (BN+act) -> split -> 16 B hi + 16 B lo
+  stage_image<F16>(src, g.Cps, 0, g.Cps >> 2, sG, g.P, g.C8, g.magicC8, sP, g.ppitch, g.lo_off, prologue, sScale, sShift, pslope, t);
+
+  // per-lane row offsets of this wave's two 16-row slabs
+  const int rp0 = sR[wave * 32 + li].x, rp1 = sR[wave * 32 + 16 + li].x;
+
+  f32x4 acc[2][PNREP];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int j = 0; j < PNREP; ++j) acc[a][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int blo = n_per_blk * PB_PITCH;    // lo half of the B tile
+  for (int kb = 0; kb < g.nstages; ++kb) {
+    __syncthreads();                       // patch staged (first iteration) / previous B tile consumed
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int c = t + 256 * i;
+        if (c < n_per_blk * 8) *(uint4*)(sB + h * blo + (c >> 3) * PB_PITCH + (c & 7) * 16) = rb[h][i];
+      }
+    __syncthreads();
+    if (kb + 1 < g.nstages) load_b(kb + 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int ko = sK[kb * 8 + s * 4 + lg];
+      const uint4 ah0 = *(const uint4*)(sP + rp0 + ko), al0 = *(const uint4*)(sP + g.lo_off + rp0 + ko);
+      const uint4 ah1 = *(const uint4*)(sP + rp1 + ko), al1 = *(const uint4*)(sP + g.lo_off + rp1 + ko);
+#pragma unroll
+      for (int j = 0; j < PNREP; ++j) {
+        if (j < nrep) {
+          const char* bp = sB + (j * 16 + li) * PB_PITCH + (s * 4 + lg) * 16;
+          const uint4 bh = *(const uint4*)bp, bl = *(const uint4*)(bp + blo);
+          // smallest terms first: lo*hi and hi*lo, then hi*hi
+          acc[0][j] = mma<F16>(al0, bh, acc[0][j]);
+          acc[1][j] = mma<F16>(al1, bh, acc[1][j]);
+          acc[0][j] = mma<F16>(ah0, bl, acc[0][j]);
+          acc[1][j] = mma<F16>(ah1, bl, acc[1][j]);
+          acc[0][j] = mma<F16>(ah0, bh, acc[0][j]);
+          acc[1][j] = mma<F16>(ah1, bh, acc[1][j]);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: store + BatchNorm partial sums over VALID rows
+  int gix[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gix[a][r] = sR[wave * 32 + a * 16 + lg * 4 + r].y;
+  __syncthreads();
+  float* red = (float*)sP;   // [4 waves][2][PNREP*16]
+#pragma unroll
+  for (int j = 0; j < PNREP; ++j) {
+    if (j < nrep) {
+      const int col = n0 + j * 16 + li;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int gi = gix[a][r];
+          if (gi >= 0) {
+            float v = acc[a][j][r];
+            s1 += v; s2 = fmaf(v, v, s2);
+            if (col < g.Cpd) {
+              float* p = dst + (size_t)gi * g.Cpd + col;
+              if (accumulate) v += *p;
+              *p = v;
+            }
+          }
+        }
+      if (stat_partial != nullptr) {
+        s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+        if (lg == 0) {
+          red[(wave * 2 + 0) * (PNREP * 16) + j * 16 + li] = s1;
+          red[(wave * 2 + 1) * (PNREP * 16) + j * 16 + li] = s2;
+        }
+      }
+    }
+  }
+  if (stat_partial != nullptr) {
+    __syncthreads();
+    if (t < ncols && n0 + t < g.Cpd) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        s1 += red[(w * 2 + 0) * (PNREP * 16) + t];
+        s2 += red[(w * 2 + 1) * (PNREP * 16) + t];
+      }
+      float* sp = stat_partial + (size_t)blockIdx.x * 2 * g.Cpd;
+      sp[n0 + t] = s1;
+      sp[g.Cpd + n0 + t] = s2;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing for k_conv_patch: [stage][hi|lo][n (N16)][8 chunks][8 bf16], K order = (tap, 8-channel chunk).
+// mode 0 (forward): n = cout, channel = cin, tap as is.  mode 1 (data gradient): n = cin, channel = cout,
+// tap reversed (the patch walks the flipped filter).
+// ------------------------------------------------------------------------------------------------
+__global__ void k_pack_weights_x3(const float* __restrict__ w, int Cout, int Cin, int taps, int mode, int C8, int nstages,
+                                  int N16, unsigned short* __restrict__ out, int f16) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;     // over [stage][n][64]
+  const int total = nstages * N16 * 64;
+  if (idx >= total) return;
+  const int e64 = idx & 63; const int r = idx >> 6;
+  const int n = r % N16; const int kb = r / N16;
+  const int q = kb * 8 + (e64 >> 3);
+  const int tap = q / C8; const int ch = (q - tap * C8) * 8 + (e64 & 7);
+  float v = 0.f;
+  if (tap < taps) {
+    if (mode == 0) { if (n < Cout && ch < Cin) v = w[((size_t)n * Cin + ch) * taps + tap]; }
+    else { if (n < Cin && ch < Cout) v = w[((size_t)ch * Cin + n) * taps + (taps - 1 - tap)]; }
+  }
+  const size_t o_hi = ((size_t)(kb * 2 + 0) * N16 + n) * 64 + e64;
+  const size_t o_lo = ((size_t)(kb * 2 + 1) * N16 + n) * 64 + e64;
+  if (f16) {
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    out[o_hi] = __builtin_bit_cast(unsigned short, hi);
+    out[o_lo] = __builtin_bit_cast(unsigned short, lo);
+  } else {
+    const __bf16 hi = (__bf16)v;
+    const __bf16 lo = (__bf16)(v - (float)hi);
+    out[o_hi] = __builtin_bit_cast(unsigned short, hi);
+    out[o_lo] = __builtin_bit_cast(unsigned short, lo);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static int pitch_for(int C8) {          // smallest 16*(4m+2) >= 16*C8
+  int u = C8;
+  while ((u & 3) != 2) ++u;
+  return u * 16;
+}
+
+// Choose the output box (bt,by,bx), <= 128 pixels, minimising (boxes) x (MFMA rows + weighted patch pixels).
+static void choose_box(int T, int H, int W, int kt, int kh, int kw, int st, int sh, int sw, int* bt, int* by, int* bx) {
+  double best = 1e300;
+  for (int t = 1; t <= T && t <= 32; ++t) {
+    for (int x = 1; x <= 128; x *= 2) {
+      const int xe = x >= W ? W : x;     // powers of two, and the full width
+      int ymax = PM / (t * xe);
+      if (ymax < 1) continue;
+      if (ymax > H) ymax = H;
+      for (int y = ymax; y >= 1 && y >= ymax - 1; --y) {
+        const double boxes = (double)md_cdiv(T, t) * md_cdiv(H, y) * md_cdiv(W, xe);
+        const double patch = (double)((t - 1) * st + kt) * ((y - 1) * sh + kh) * ((xe - 1) * sw + kw);
+        const double cost = boxes * (PM + 0.6 * patch);
+        if (cost < best) { best = cost; *bt = t; *by = y; *bx = xe; }
+      }
+      if (x >= W) break;
+    }
+  }
+}
+
+static bool patch_build(const MdConvDesc* d, int dgrad, PGeom* out, size_t* lds_bytes) {
+  if (dgrad && (d->st != 1 || d->sh != 1 || d->sw != 1)) return false;
+  PGeom g;
+  g.st = dgrad ? 1 : d->st; g.sh = dgrad ? 1 : d->sh; g.sw = dgrad ? 1 : d->sw;
+  const int cs = dgrad ? d->Cout : d->Cin, cd = dgrad ? d->Cin : d->Cout;
+  g.Ts = dgrad ? d->To : d->Ti; g.Hs = dgrad ? d->Ho : d->Hi; g.Ws = dgrad ? d->Wo : d->Wi; g.Cps = md_cpad(cs);
+  g.Td = dgrad ? d->Ti : d->To; g.Hd = dgrad ? d->Hi : d->Ho; g.Wd = dgrad ? d->Wi : d->Wo; g.Cpd = md_cpad(cd);
+  g.kh = d->kh; g.kw = d->kw; g.khw = d->kh * d->kw; g.taps = d->kt * g.khw;
+  if (!dgrad) { g.org_t = -d->pt; g.org_h = -d->ph; g.org_w = -d->pw; }
+  else { g.org_t = d->pt - (d->kt - 1); g.org_h = d->ph - (d->kh - 1); g.org_w = d->pw - (d->kw - 1); }
+  choose_box(g.Td, g.Hd, g.Wd, d->kt, d->kh, d->kw, g.st, g.sh, g.sw, &g.bt, &g.by, &g.bx);
+  g.byx = g.by * g.bx;
+  g.nbt = md_cdiv(g.Td, g.bt); g.nby = md_cdiv(g.Hd, g.by); g.nbx = md_cdiv(g.Wd, g.bx);
+  g.pt = (g.bt - 1) * g.st + d->kt; g.py = (g.by - 1) * g.sh + d->kh; g.px = (g.bx - 1) * g.sw + d->kw;
+  g.pyx = g.py * g.px; g.P = g.pt * g.pyx;
+  g.C8 = (g.Cps + 7) / 8;
+  g.ppitch = pitch_for(g.C8);
+  g.lo_off = (g.P * g.ppitch + 15) & ~15;
+  g.Kc8 = g.taps * g.C8;
+  g.nstages = md_cdiv(g.Kc8, 8);
+  g.N16 = md_round_up(cd, 16);
+  g.magicC8 = g.C8 == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)g.C8) + 1u;
+  if ((long long)g.P * g.C8 >= 65536 || g.Cps > PMAXC) return false;
+  size_t off = (size_t)2 * g.lo_off;
+  const size_t red = (size_t)4 * 2 * PNREP * 16 * 4;      // epilogue reduction scratch aliases the patch
+  if (off < red) off = red;
+  const int nchunks_ = md_cdiv(g.N16, PNREP * 16);
+  const int npb_ = md_round_up(md_cdiv(g.N16, nchunks_), 16);
+  g.off_b = (int)off; off += (size_t)2 * npb_ * PB_PITCH;
+  g.off_koffs = (int)off; off += (size_t)g.nstages * 8 * 4;
+  g.off_rows = (int)off; off += (size_t)PM * 8;
+  g.off_pixg = (int)off; off += (size_t)((g.P * 4 + 15) & ~15);
+  g.off_scale = (int)off; off += (size_t)2 * PMAXC * 4;
+  if (off > 160 * 1024) return false;
+  *out = g; *lds_bytes = off;
+  return true;
+}
+
+struct PatchPlan { PGeom g; size_t lds; int N; int dgrad; };
+
+#include <map>
+#include <mutex>
+#include <array>
+#include <atomic>
+#include <cstdlib>
+static std::atomic<int> g_exact_fp32{0};
+extern "C" int md_set_exact_fp32(int on) { int old = g_exact_fp32.exchange(on ? 1 : 0); return old; }
+extern "C" int md_get_exact_fp32(void) { return g_exact_fp32.load(); }
+
+const PatchPlan* patch_lookup(const MdConvDesc* d, int dgrad) {
+  if (g_exact_fp32.load()) return nullptr;     // exact mode: every convolution on the fp32-MFMA gather kernels
+  {   // debugging aid: MD_PATCH_FWD=0 / MD_PATCH_DGRAD=0 route one direction to the generic kernel
+    static const int dis_f = getenv("MD_PATCH_FWD") && atoi(getenv("MD_PATCH_FWD")) == 0;
+    static const int dis_d = getenv("MD_PATCH_DGRAD") && atoi(getenv("MD_PATCH_DGRAD")) == 0;
+    if ((dgrad && dis_d) || (!dgrad && dis_f)) return nullptr;
+  }
+  static std::mutex mu;
+  static std::map<std::array<int, 19>, PatchPlan*> cache;    // value nullptr = does not qualify
+  std::array<int, 19> key = {d->N, d->Ti, d->Hi, d->Wi, d->Cin, d->To, d->Ho, d->Wo, d->Cout, d->kt, d->kh, d->kw,
+                             d->st, d->sh, d->sw, d->pt, d->ph, d->pw, dgrad};
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  PatchPlan* pp = nullptr;
+  PGeom g; size_t lds = 0;
+  if (patch_build(d, dgrad, &g, &lds)) { pp = new PatchPlan(); pp->g = g; pp->lds = lds; pp->N = d->N; pp->dgrad = dgrad; }
+  cache[key] = pp;
+  return pp;
+}
+
+size_t patch_wpack_floats(const PatchPlan* p) { return (size_t)p->g.nstages * 2 * p->g.N16 * 64 / 2; }   // bf16 count / 2
+int patch_blocks(const PatchPlan* p) { return p->N * p->g.nbt * p->g.nby * p->g.nbx; }
+
+int patch_pack(const MdConvDesc* d, int dgrad, const PatchPlan* p, const float* w, float* out, hipStream_t s) {
+  const PGeom& g = p->g;
+  const int total = g.nstages * g.N16 * 64;
+  hipLaunchKernelGGL(k_pack_weights_x3, dim3(md_cdiv(total, 256)), dim3(256), 0, s, w, d->Cout, d->Cin, g.taps, dgrad, g.C8,
+                     g.nstages, g.N16, (unsigned short*)out, dgrad ? 0 : 1);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+int patch_launch(const PatchPlan* p, const float* src, const float* ps, const float* psh, float slope, const float* wp,
+                 float* dst, float* stat, int accumulate, hipStream_t s) {
+  const PGeom& g = p->g;
+  const int nchunks = md_cdiv(g.N16, PNREP * 16);
+  const int npb = md_round_up(md_cdiv(g.N16, nchunks), 16);
+  dim3 grid(patch_blocks(p), md_cdiv(g.N16, npb));
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)k_conv_patch<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_conv_patch<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return MD_ERR_LAUNCH;
+    attr_set = true;
+  }
+  if (p->dgrad)
+    hipLaunchKernelGGL(k_conv_patch<false>, grid, dim3(256), p->lds, s, g, src, ps, psh, slope, (const uint4*)wp, dst, stat,
+                       accumulate, npb);
+  else
+    hipLaunchKernelGGL(k_conv_patch<true>, grid, dim3(256), p->lds, s, g, src, ps, psh, slope, (const uint4*)wp, dst, stat,
+                       accumulate, npb);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+// ================================================================================================
+// Weight gradient of a unit-stride convolution, split-bf16 arithmetic, LDS-resident operands.
+//   dW[k = (tap, cin)][cout] = sum over pixels  X[pixel + tap][cin] * dY[pixel][cout]
+// A workgroup walks a slice of the output boxes.  Per box it stages the X patch (with halo, BN-on-read) and the
+// dY box once, both as [pixel][channel] bf16 hi|lo images.  The reduction axis of the MFMA is the pixel axis,
+// which is the SLOW axis of both images, so both operands are fetched with ds_read_b64_tr_b16: a 16-lane group
+// reads 4 pixels x 16 channels and each lane receives its channel for those 4 pixels -- the transpose is free
+// and no second copy of either operand exists.  Wave w owns `ktw` 16-row k-tiles x `nrep` 16-col n-tiles
+// (<= 25 accumulator tiles); partial results go to a per-slice slab and k_wgrad_reduce sums the slabs in a fixed
+// order straight into the reference's (Cout,Cin,kt,kh,kw) layout (deterministic, no atomics).
+// ================================================================================================
+#define WKT 5
+#define WNR 5
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+struct WGeom {
+  int Ti, Hi, Wi, Cpi;        // X
+  int To, Ho, Wo, Cpo;        // dY
+  int kh, kw, khw, taps;
+  int org_t, org_h, org_w;
+  int st, sh, sw;
+  int bt, by, bx, byx, nbt, nby, nbx;
+  int pt, py, px, pyx, P;
+  int C8i, ppitch, lo_off;    // X patch image (C8i even: whole 16-channel k-tiles)
+  int NC, ypitch, ylo_off;    // dY image: NC = 2*nrep chunks per row
+  int KT, nkt;                // 16-channel k-tiles per tap, total
+  int ktw, nrep, nkg, nng;
+  int nboxes, boxes_per_wg;
+  int N16;
+  unsigned magicC8, magicNC;
+  int off_y, off_rows, off_pixg, off_scale;
+};
+
+__device__ __forceinline__ bf16x8 tr_read2(const char* p0, const char* p1) {
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p0);
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p1);
+  s16x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+__global__ __launch_bounds__(256) void k_wgrad_patch(
+    WGeom g, const float* __restrict__ src, const float* __restrict__ pscale, const float* __restrict__ pshift,
+    float pslope, const float* __restrict__ dy, float* __restrict__ slab) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  char* sP = sm;
+  char* sY = sm + g.off_y;
+  int2* sR = (int2*)(sm + g.off_rows);          // [PM] {X patch byte offset of the row, dY global pixel or -1}
+  int* sG = (int*)(sm + g.off_pixg);
+  int* sGY = sG + ((g.P + 3) & ~3);             // [PM] dY pixel table for stage_image
+  float* sScale = (float*)(sm + g.off_scale);
+  float* sShift = sScale + PMAXC;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int lq = li >> 2, lp = li & 3;
+  const int kg = blockIdx.y / g.nng, ng = blockIdx.y - kg * g.nng;
+  const int n0 = ng * g.nrep * 16;              // first dY channel of this workgroup
+  const int kt0 = (kg * 4 + wave) * g.ktw;      // first k-tile of this wave
+  const bool prologue = pscale != nullptr;
+  if (prologue) for (int c = t; c < g.Cpi; c += 256) { sScale[c] = pscale[c]; sShift[c] = pshift[c]; }
+
+  f32x4 acc[WKT][WNR];
+#pragma unroll
+  for (int a = 0; a < WKT; ++a)
+#pragma unroll
+    for (int j = 0; j < WNR; ++j) acc[a][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // byte offset inside the X patch of each of this wave's k-tiles: tap pixel offset + 32 B per 16 channels
+  int koff[WKT];
+#pragma unroll
+  for (int a = 0; a < WKT; ++a) {
+    const int kt = kt0 + a;
+    int o = 0;
+    if (a < g.ktw && kt < g.nkt) {
+      const int tap = kt / g.KT; const int c16 = kt - tap * g.KT;
+      const int dt = tap / g.khw; const int r = tap - dt * g.khw;
+      const int dyy = r / g.kw; const int dxx = r - dyy * g.kw;
+      o = ((dt * g.py + dyy) * g.px + dxx) * g.ppitch + c16 * 32;
+    }
+    koff[a] = o;
+  }
+
+  const int box_beg = blockIdx.x * g.boxes_per_wg;
+  const int box_end = min(g.nboxes, box_beg + g.boxes_per_wg);
+  const int ycv4 = max(0, min(g.NC * 2, (g.Cpo - n0) >> 2));      // valid float4 units of a dY row from n0
+  for (int box = box_beg; box < box_end; ++box) {
+    int b = box;
+    const int xb = b % g.nbx; b /= g.nbx;
+    const int yb = b % g.nby; b /= g.nby;
+    const int tb = b % g.nbt; const int n = b / g.nbt;
+    const int t0 = tb * g.bt, y0 = yb * g.by, x0 = xb * g.bx;
+    __syncthreads();          // previous box fully consumed
+    for (int p = t; p < g.P; p += 256) {
+      const int ppt = p / g.pyx; const int r = p - ppt * g.pyx;
+      const int ppy = r / g.px; const int ppx = r - ppy * g.px;
+      const int st = t0 * g.st + g.org_t + ppt, sy = y0 * g.sh + g.org_h + ppy, sx = x0 * g.sw + g.org_w + ppx;
+      const bool v = ((unsigned)st < (unsigned)g.Ti) && ((unsigned)sy < (unsigned)g.Hi) && ((unsigned)sx < (unsigned)g.Wi);
+      sG[p] = v ? ((n * g.Ti + st) * g.Hi + sy) * g.Wi + sx : -1;
+    }
+    if (t < PM) {
+      const int rt = t / g.byx; const int r = t - rt * g.byx;
+      const int ry = r / g.bx; const int rx = r - ry * g.bx;
+      const bool v = (rt < g.bt) && (t0 + rt < g.To) && (y0 + ry < g.Ho) && (x0 + rx < g.Wo);
+      int2 ri;
+      ri.x = v ? ((rt * g.st * g.py + ry * g.sh) * g.px + rx * g.sw) * g.ppitch : 0;
+      ri.y = v ? ((n * g.To + t0 + rt) * g.Ho + y0 + ry) * g.Wo + x0 + rx : -1;
+      sR[t] = ri;
+      sGY[t] = ri.y;
+    }
+    __syncthreads();
+    stage_image<false>(src, g.Cpi, 0, g.Cpi >> 2, sG, g.P, g.C8i, g.magicC8, sP, g.ppitch, g.lo_off, prologue, sScale, sShift,
+                pslope, t);
+    stage_image<false>(dy, g.Cpo, n0, ycv4, sGY, PM, g.NC, g.magicNC, sY, g.ypitch, g.ylo_off, false, nullptr, nullptr, 1.f, t);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int r0 = s * 32 + lg * 8 + lq;                 // this lane's address row of the first 4-pixel block
+      const int xa = sR[r0].x + lp * 8, xb2 = sR[r0 + 4].x + lp * 8;
+      const int ya = r0 * g.ypitch + lp * 8, yb2 = (r0 + 4) * g.ypitch + lp * 8;
+      bf16x8 bh[WNR], bl[WNR];
+#pragma unroll
+      for (int j = 0; j < WNR; ++j) {
+        if (j < g.nrep) {
+          bh[j] = tr_read2(sY + ya + j * 32, sY + yb2 + j * 32);
+          bl[j] = tr_read2(sY + g.ylo_off + ya + j * 32, sY + g.ylo_off + yb2 + j * 32);
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < WKT; ++a) {
+        if (a < g.ktw) {
+          const bf16x8 ah = tr_read2(sP + xa + koff[a], sP + xb2 + koff[a]);
+          const bf16x8 al = tr_read2(sP + g.lo_off + xa + koff[a], sP + g.lo_off + xb2 + koff[a]);
+#pragma unroll
+          for (int j = 0; j < WNR; ++j) {
+            if (j < g.nrep) {
+              acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[a][j], 0, 0, 0);
+              acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[a][j], 0, 0, 0);
+              acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[a][j], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- slab[slice][k16 row][N16]: D rows = k index (4*lg + reg), cols = cout (li)
+  float* out = slab + (size_t)blockIdx.x * g.nkt * 16 * g.N16;
+#pragma unroll
+  for (int a = 0; a < WKT; ++a) {
+    const int kt = kt0 + a;
+    if (a < g.ktw && kt < g.nkt) {
+#pragma unroll
+      for (int j = 0; j < WNR; ++j) {
+        if (j < g.nrep) {
+          const int col = n0 + j * 16 + li;
+          if (col < g.N16) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(size_t)(kt * 16 + lg * 4 + r) * g.N16 + col] = acc[a][j][r];
+          }
+        }
+      }
+    }
+  }
+}
+
+// dw[cout][cin][tap] = sum_slices slab[slice][(tap*KT + cin/16)*16 + cin%16][cout]   (fixed order)
+// Block = 64 outputs x 4 slice groups: slice group q sums slices q, q+4, ... with four independent chains.
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slab, int nslices, int nkt, int KT, int N16,
+                                                      int Cout, int Cin, int taps, float* __restrict__ dw) {
+  __shared__ float red[4][64];
+  const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + o;                         // over [k16 rows][N16], cout fastest
+  const int rows = nkt * 16;
+  const size_t stride = (size_t)rows * N16;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (idx < rows * N16) {
+    int i = q;
+    for (; i + 12 < nslices; i += 16) {
+      s0 += slab[(size_t)i * stride + idx];
+      s1 += slab[(size_t)(i + 4) * stride + idx];
+      s2 += slab[(size_t)(i + 8) * stride + idx];
+      s3 += slab[(size_t)(i + 12) * stride + idx];
+    }
+    for (; i < nslices; i += 4) s0 += slab[(size_t)i * stride + idx];
+  }
+  red[q][o] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (q == 0 && idx < rows * N16) {
+    const float s = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
+    const int krow = idx / N16, co = idx - krow * N16;
+    const int kt = krow >> 4; const int tap = kt / KT; const int c = (kt - tap * KT) * 16 + (krow & 15);
+    if (co < Cout && c < Cin) dw[((size_t)co * Cin + c) * taps + tap] = s;
+  }
+}
+
+struct WgradPlan { WGeom g; size_t lds; int nslices; };
+
+static bool wgrad_build(const MdConvDesc* d, WGeom* out, size_t* lds_bytes, int* nslices) {
+  WGeom g;
+  g.st = d->st; g.sh = d->sh; g.sw = d->sw;
+  g.Ti = d->Ti; g.Hi = d->Hi; g.Wi = d->Wi; g.Cpi = md_cpad(d->Cin);
+  g.To = d->To; g.Ho = d->Ho; g.Wo = d->Wo; g.Cpo = md_cpad(d->Cout);
+  g.kh = d->kh; g.kw = d->kw; g.khw = d->kh * d->kw; g.taps = d->kt * g.khw;
+  g.org_t = -d->pt; g.org_h = -d->ph; g.org_w = -d->pw;
+  choose_box(g.To, g.Ho, g.Wo, d->kt, d->kh, d->kw, g.st, g.sh, g.sw, &g.bt, &g.by, &g.bx);
+  g.byx = g.by * g.bx;
+  g.nbt = md_cdiv(g.To, g.bt); g.nby = md_cdiv(g.Ho, g.by); g.nbx = md_cdiv(g.Wo, g.bx);
+  g.pt = (g.bt - 1) * g.st + d->kt; g.py = (g.by - 1) * g.sh + d->kh; g.px = (g.bx - 1) * g.sw + d->kw;
+  g.pyx = g.py * g.px; g.P = g.pt * g.pyx;
+  g.KT = md_cdiv(d->Cin, 16); g.nkt = g.taps * g.KT;
+  g.C8i = 2 * g.KT;
+  g.ppitch = pitch_for(g.C8i);
+  g.lo_off = (g.P * g.ppitch + 15) & ~15;
+  g.N16 = md_round_up(d->Cout, 16);
+  const int NT = g.N16 / 16;
+  g.nng = md_cdiv(NT, WNR); g.nrep = md_cdiv(NT, g.nng);
+  g.ktw = md_cdiv(g.nkt, 4); if (g.ktw > WKT) g.ktw = WKT;
+  g.nkg = md_cdiv(g.nkt, 4 * g.ktw);
+  g.NC = 2 * g.nrep;
+  g.ypitch = pitch_for(g.NC);
+  g.ylo_off = PM * g.ypitch;
+  g.magicC8 = g.C8i == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)g.C8i) + 1u;
+  g.magicNC = g.NC == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)g.NC) + 1u;
+  g.nboxes = d->N * g.nbt * g.nby * g.nbx;
+  if ((long long)g.P * g.C8i >= 65536 || g.Cpi > PMAXC) return false;
+  // enough workgroups to fill the chip, few enough that the slabs stay small
+  int want = md_cdiv(512, g.nkg * g.nng);
+  if (want > g.nboxes) want = g.nboxes;
+  if (want < 1) want = 1;
+  g.boxes_per_wg = md_cdiv(g.nboxes, want);
+  *nslices = md_cdiv(g.nboxes, g.boxes_per_wg);
+  size_t off = (size_t)2 * g.lo_off;
+  g.off_y = (int)off; off += (size_t)2 * g.ylo_off;
+  g.off_rows = (int)off; off += (size_t)PM * 8;
+  g.off_pixg = (int)off; off += (size_t)(((g.P + 3) & ~3) + PM) * 4;
+  off = (off + 15) & ~(size_t)15;
+  g.off_scale = (int)off; off += (size_t)2 * PMAXC * 4;
+  if (off > 160 * 1024) return false;
+  *out = g; *lds_bytes = off;
+  return true;
+}
+
+const WgradPlan* wgrad_lookup(const MdConvDesc* d) {
+  if (g_exact_fp32.load()) return nullptr;
+  static const int dis = getenv("MD_PATCH_WGRAD") && atoi(getenv("MD_PATCH_WGRAD")) == 0;
+  if (dis) return nullptr;
+  static std::mutex mu;
+  static std::map<std::array<int, 18>, WgradPlan*> cache;
+  std::array<int, 18> key = {d->N, d->Ti, d->Hi, d->Wi, d->Cin, d->To, d->Ho, d->Wo, d->Cout, d->kt, d->kh, d->kw,
+                             d->st, d->sh, d->sw, d->pt, d->ph, d->pw};
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  WgradPlan* wp = nullptr;
+  WGeom g; size_t lds = 0; int ns = 0;
+  if (wgrad_build(d, &g, &lds, &ns)) { wp = new WgradPlan(); wp->g = g; wp->lds = lds; wp->nslices = ns; }
+  cache[key] = wp;
+  return wp;
+}
+
+size_t wgrad_patch_workspace_floats(const WgradPlan* p) { return (size_t)p->nslices * p->g.nkt * 16 * p->g.N16; }
+
+int wgrad_patch_launch(const WgradPlan* p, const MdConvDesc* d, const float* src, const float* ps, const float* psh,
+                       float slope, const float* dy, float* dw, float* slab, hipStream_t s) {
+  const WGeom& g = p->g;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)k_wgrad_patch, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return MD_ERR_LAUNCH;
+    attr_set = true;
+  }
+  dim3 grid(p->nslices, g.nkg * g.nng);
+  hipLaunchKernelGGL(k_wgrad_patch, grid, dim3(256), p->lds, s, g, src, ps, psh, slope, dy, slab);
+  MD_CHECK_LAUNCH();
+  const int total = g.nkt * 16 * g.N16;
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(md_cdiv(total, 64)), dim3(256), 0, s, slab, p->nslices, g.nkt, g.KT, g.N16, d->Cout,
+                     d->Cin, g.taps, dw);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}

@@ -47,7 +47,7 @@ struct MdPlan {
   std::vector<Unit> units;
   std::vector<Block> blocks;
   std::vector<ZT> z;
-  size_t part_off, coef_off, g_off[4], gmax, total_floats;
+  size_t part_off, coef_off, slab_off, g_off[4], gmax, total_floats;
   size_t part_floats;
   int feat_dim;
   int bwd_p;   // gradient buffer currently holding dZ
@@ -136,6 +136,9 @@ extern "C" int md_plan_create(int32_t B, int32_t T, int32_t H, int32_t W, const 
   }
   P->part_floats = pmax;
   P->part_off = take(pmax);
+  size_t smax = 0;
+  for (auto& u : P->units) { const size_t n = md_conv_wgrad_workspace_floats(&u.d); if (n > smax) smax = n; }
+  P->slab_off = take(smax);
   P->coef_off = take(2 * 1024);
   P->gmax = gmax;
   for (int i = 0; i < 4; ++i) P->g_off[i] = take(gmax);
@@ -277,11 +280,9 @@ static int unit_backward(MdPlan* P, float* ws, int ui, int gb, int dxb, int accu
     RC(md_bn_bwd_finalize(ws + P->part_off, nb, u.d.Cout, u.rows, dgamma[ui], dbeta[ui], ws + P->coef_off, stream));
     RC(md_bn_bwd_apply(G, &mainv, nullptr, 1.f, st, st + u.Cp, ws + P->coef_off, u.rows, u.d.Cout, G, nullptr, stream));
   }
-  const size_t wn = (size_t)u.d.Cout * u.d.Cin * u.d.kt * u.d.kh * u.d.kw;
-  if (hipMemsetAsync(dw[ui], 0, wn * 4, (hipStream_t)stream) != hipSuccess) return MD_ERR_LAUNCH;
   MdActView in = unit_in_view(P, ws, ui);
   { ProfScope ps(P, KC_WGRAD, unit_flops(u), stream);
-    RC(md_conv_wgrad(&u.d, &in, G, dw[ui], stream)); }
+    RC(md_conv_wgrad(&u.d, &in, G, dw[ui], ws + P->slab_off, stream)); }
   if (dxb >= 0) {
     ProfScope ps(P, KC_DGRAD, unit_flops(u), stream);
     RC(md_conv_dgrad(&u.d, G, ws + u.wd_off, ws + P->g_off[dxb], accumulate, stream));

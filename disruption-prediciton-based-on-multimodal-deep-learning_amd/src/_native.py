@@ -31,13 +31,16 @@ _I32, _I64, _F, _SZ = C.c_int32, C.c_int64, C.c_float, C.c_size_t
 _DESC, _VIEW = C.POINTER(MdConvDesc), C.POINTER(MdActView)
 SIGNATURES = {
     "md_version": (C.c_int, [C.POINTER(C.c_char_p)]),
+    "md_set_exact_fp32": (C.c_int, [C.c_int]),
+    "md_get_exact_fp32": (C.c_int, []),
     "md_conv_wpack_fwd_floats": (_SZ, [_DESC]),
     "md_conv_wpack_dgrad_floats": (_SZ, [_DESC]),
     "md_conv_pack_weights": (C.c_int, [_DESC, _P, _P, _P, _P]),
     "md_conv_fwd_stat_blocks": (_I32, [_DESC]),
     "md_conv_fwd": (C.c_int, [_DESC, _VIEW, _P, _P, _P, _P]),
     "md_conv_dgrad": (C.c_int, [_DESC, _P, _P, _P, C.c_int, _P]),
-    "md_conv_wgrad": (C.c_int, [_DESC, _VIEW, _P, _P, _P]),
+    "md_conv_wgrad_workspace_floats": (_SZ, [_DESC]),
+    "md_conv_wgrad": (C.c_int, [_DESC, _VIEW, _P, _P, _P, _P]),
     "md_bn_finalize": (C.c_int, [_P, _I32, _I32, _I64, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
     "md_bn_eval_params": (C.c_int, [_I32, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P]),
     "md_bn_act": (C.c_int, [_VIEW, _I64, _I32, _P, _P]),

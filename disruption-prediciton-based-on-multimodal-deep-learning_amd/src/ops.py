@@ -15,6 +15,11 @@ import torch
 from . import _native as N
 
 
+def set_exact_fp32(on: bool) -> bool:
+    """Process-wide arithmetic mode of the convolutions (see md_set_exact_fp32); returns the previous mode."""
+    return bool(N.lib().md_set_exact_fp32(int(bool(on))))
+
+
 def cpad(c: int) -> int:
     return (c + 3) & ~3
 
@@ -111,8 +116,10 @@ def conv_dgrad(d: N.MdConvDesc, dy: torch.Tensor, wd: torch.Tensor, out: Optiona
 
 def conv_wgrad(d: N.MdConvDesc, x: N.MdActView, dy: torch.Tensor) -> torch.Tensor:
     require_cuda(dy)
-    dw = torch.zeros((d.Cout, d.Cin, d.kt, d.kh, d.kw), device=dy.device, dtype=torch.float32)
-    N.check(N.lib().md_conv_wgrad(C.byref(d), C.byref(x), _p(dy), _p(dw), _stream()), "md_conv_wgrad")
+    dw = torch.empty((d.Cout, d.Cin, d.kt, d.kh, d.kw), device=dy.device, dtype=torch.float32)
+    nws = N.lib().md_conv_wgrad_workspace_floats(C.byref(d))
+    ws = torch.empty(nws, device=dy.device, dtype=torch.float32) if nws else None
+    N.check(N.lib().md_conv_wgrad(C.byref(d), C.byref(x), _p(dy), _p(dw), _p(ws), _stream()), "md_conv_wgrad")
     return dw
 
 

@@ -36,6 +36,14 @@ extern "C" {
 /* Library identity: returns the ABI version; *arch_out (optional) receives "gfx950". */
 int md_version(const char** arch_out);
 
+/* Arithmetic mode of the convolutions (process-wide, default 0):
+ *   0  "bf16x3": unit-stride convolutions run on the LDS-patch kernels with every fp32 operand split into two
+ *      bf16 halves (hi+lo) and three bf16 MFMAs per product, fp32 accumulation (~5e-6 relative error per conv);
+ *   1  exact fp32: every convolution runs on v_mfma_f32_16x16x4_f32 (bitwise an fp32 fmaf chain, 1/16 the rate).
+ * Packed weights depend on the mode: change it only between steps.  Returns the previous mode. */
+int md_set_exact_fp32(int on);
+int md_get_exact_fp32(void);
+
 /* ------------------------------------------------------------------------------------------------
  * Convolution as implicit GEMM on the matrix cores (replaces nn.Conv3d fwd/bwd as used by
  * Conv3dBlock, src/models/R2Plus1D.py:44-51; covers both factors of SpatioTemporalConv :139-140,
@@ -81,9 +89,12 @@ int md_conv_fwd(const MdConvDesc* d, const MdActView* x, const float* wpack_fwd,
 int md_conv_dgrad(const MdConvDesc* d, const float* dy_raw, const float* wpack_dgrad, float* dx,
                   int accumulate, void* stream);
 
-/* dw (reference layout, must be zeroed by the caller: md_conv_wgrad accumulates with float atomics)
- * += x_view^T * dy_raw. */
-int md_conv_wgrad(const MdConvDesc* d, const MdActView* x, const float* dy_raw, float* dw, void* stream);
+/* dw (reference layout (Cout,Cin,kt,kh,kw), overwritten) = x_view^T * dy_raw.  `workspace` must hold
+ * md_conv_wgrad_workspace_floats(d) floats (per-slice partial sums, reduced in a fixed order); it may be NULL
+ * when that size is 0 (the strided / exact-fp32 path accumulates with float atomics instead). */
+size_t md_conv_wgrad_workspace_floats(const MdConvDesc* d);
+int md_conv_wgrad(const MdConvDesc* d, const MdActView* x, const float* dy_raw, float* dw, float* workspace,
+                  void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm3d (train mode) + LeakyReLU + residual: everything between two convolutions

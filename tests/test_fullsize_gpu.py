@@ -1,0 +1,78 @@
+"""GPU parity at the BASELINE.json shape (T=21, 128x128, layer_sizes [1,2,2,1]) against the oracle run on the host.
+
+Forward: logits / loss within 1e-3 of the fp32 oracle in both arithmetic modes.  Gradients: relative L2 error per
+parameter against the oracle evaluated in fp64, bounded by a small multiple of the fp32 oracle's own distance to
+fp64 (the yardstick for what fp32 arithmetic can deliver on this workload).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from src import ops
+    from src.models.R2Plus1D import R2Plus1DClassifier
+    from src.loss import FocalLoss
+
+from oracle import losses as ol, r2plus1d as orc, step as ostep
+
+DEV = "cuda:0"
+LS, B, T, S, ALPHA, SEED = [1, 2, 2, 1], 4, 21, 128, 0.01, 77
+
+
+@pytest.fixture(scope="module")
+def reference():
+    torch.set_num_threads(16)
+    params, bufs = orc.synth_state(LS, SEED, ALPHA)
+    x = orc.synth_clip(B, T, S, SEED); y = orc.synth_labels(B, SEED)
+    w = torch.ones(2)
+    logits, loss, grads = ostep.r2plus1d_loss_and_grads(x, y, params, bufs, LS, ALPHA, lambda o, t: ol.focal_loss(o, t, w, 2.0))
+    # the same oracle in fp64: the yardstick for how much of a deviation is fp32 rounding noise of the CPU path itself
+    p64 = {k: v.double() for k, v in params.items()}
+    b64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in orc.synth_state(LS, SEED, ALPHA)[1].items()}
+    _, _, g64 = ostep.r2plus1d_loss_and_grads(x.double(), y, p64, b64, LS, ALPHA, lambda o, t: ol.focal_loss(o, t, w.double(), 2.0))
+    return x, y, logits, loss, grads, g64
+
+
+@pytest.mark.parametrize("exact", [False, True], ids=["split", "exact_fp32"])
+def test_fullsize_forward_backward(reference, exact):
+    x, y, ref_logits, ref_loss, ref_g, g64 = reference
+    ops.set_exact_fp32(exact)
+    try:
+        model = R2Plus1DClassifier(input_size=(3, T, S, S), num_classes=2, layer_sizes=LS, alpha=ALPHA)
+        params, bufs = orc.synth_state(LS, SEED, ALPHA)
+        sd = dict(params); sd.update(bufs)
+        model.load_state_dict(sd, strict=True)
+        model.to(DEV).train()
+        loss_fn = FocalLoss(weight=torch.ones(2), gamma=2.0)
+        logits = model(x.to(DEV))
+        loss = loss_fn(logits, y.to(DEV))
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_exact_fp32(False)
+    lerr = float((logits.detach().cpu() - ref_logits).abs().max() / ref_logits.abs().max())
+    assert lerr < 1e-3, lerr
+    assert abs(loss.item() - float(ref_loss)) < 1e-3 * max(1.0, abs(float(ref_loss)))
+    worst, worst_name, errs, errs32, cpu_noise = 0.0, "", [], [], []
+    gmax = max(float(v.norm()) for v in g64.values())
+    for k, p in model.named_parameters():
+        if k == "linear.0.bias":
+            continue
+        r = g64[k]
+        den = max(float(r.norm()), 1e-6 * gmax)
+        e = float((p.grad.cpu().double() - r).norm() / den)
+        errs.append(e)
+        errs32.append(float((p.grad.cpu() - ref_g[k]).norm() / den))
+        cpu_noise.append(float((ref_g[k].double() - r).norm() / den))
+        if e > worst:
+            worst, worst_name = e, k
+    print(f"mode={'exact' if exact else 'split'} logits relerr {lerr:.2e}; gradient rel-L2 vs fp64 oracle: median "
+          f"{np.median(errs):.2e} worst {worst:.2e} ({worst_name}); vs fp32 oracle: median {np.median(errs32):.2e}; "
+          f"fp32 oracle vs fp64 oracle: median {np.median(cpu_noise):.2e} worst {max(cpu_noise):.2e}")
+
+    # This workload is ill conditioned for gradients at B=4 (the head's BatchNorm1d sees 4 samples): the fp32 CPU
+    # oracle itself sits `cpu_noise` (~5e-3) away from its fp64 evaluation.  Hold the HIP path to the same order.
+    assert np.median(errs) < max(2e-3, 4.0 * float(np.median(cpu_noise))), (np.median(errs), np.median(cpu_noise))
+    assert worst < max(1e-2, 5.0 * max(cpu_noise)), (worst, max(cpu_noise))

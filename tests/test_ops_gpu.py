@@ -87,7 +87,7 @@ def test_conv_fwd_dgrad_wgrad(case, prologue):
     yg, part = ops.conv_fwd(d, v, wf, DEV, want_stats=True)
     torch.cuda.synchronize()
     y_hip = uncl(yg.cpu(), Cout)
-    assert relerr(y_hip, y.detach()) < 2e-5
+    assert relerr(y_hip, y.detach()) < 3e-5
     # pad channels stay exactly zero
     assert float(yg[..., Cout:].abs().max().cpu()) == 0.0 if yg.shape[-1] > Cout else True
     # BN partial statistics from the epilogue
@@ -100,7 +100,7 @@ def test_conv_fwd_dgrad_wgrad(case, prologue):
     dx = ops.conv_dgrad(d, dyg, wd)
     dw = ops.conv_wgrad(d, v, dyg)
     torch.cuda.synchronize()
-    assert relerr(uncl(dx.cpu(), Cin), a.grad) < 2e-5
+    assert relerr(uncl(dx.cpu(), Cin), a.grad) < 3e-5
     assert relerr(dw.cpu(), wr.grad) < 2e-5
     # accumulate form: dx2 = dx + dgrad
     dx2 = ops.conv_dgrad(d, dyg, wd, out=dx.clone(), accumulate=True)

@@ -32,6 +32,11 @@ struct PGeom {
   int kh, kw, khw, taps;
   int org_t, org_h, org_w;  // source coordinate = box origin * stride + org + patch coordinate
   int st, sh, sw;           // stride of the (forward) convolution; 1 for the data gradient
+  int strided;              // 1: data gradient of a strided convolution (per-tap divisibility test)
+  int dst_, dsh_, dsw_;     // the convolution's stride (strided data gradient)
+  int lt, lh, lw, oddmask;  // log2 strides; packed mask of the low bits that must be zero
+  int kt, padt, padh, padw;
+  int zero_off;             // byte offset of the all-zero pixel
   int bt, by, bx, byx;      // output box
   int nbt, nby, nbx;        // boxes per clip
   int pt, py, px, pyx, P;   // patch dims
@@ -145,7 +150,7 @@ __device__ __forceinline__ f32x4 mma(uint4 a, uint4 b, f32x4 c) {
 
 // F16 = true: forward convolution, operands split into fp16 halves (activations/weights are O(1) quantities);
 // F16 = false: data gradient, operands split into bf16 halves (gradients need bf16's exponent range).
-template <bool F16>
+template <bool F16, bool STRIDED>
 __global__ __launch_bounds__(256) void k_conv_patch(
     PGeom g, const float* __restrict__ src, const float* __restrict__ pscale, const float* __restrict__ pshift,
     float pslope, const uint4* __restrict__ wp, float* __restrict__ dst, float* __restrict__ stat_partial,
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(256) void k_conv_patch(
   char* sP = sm;                                   // patch hi | lo
   char* sB = sm + g.off_b;                         // B tile hi [n][160 B] | lo
   int* sK = (int*)(sm + g.off_koffs);              // [nstages*8]
-  int2* sR = (int2*)(sm + g.off_rows);             // [PM] {rowpix bytes, global dst pixel or -1}
+  int4* sR = (int4*)(sm + g.off_rows);             // [PM] {rowpix bytes, global dst pixel or -1, packed row numerators, -}
   int* sG = (int*)(sm + g.off_pixg);               // [P] global source pixel or -1
   float* sScale = (float*)(sm + g.off_scale);      // [Cps] scale | shift
   float* sShift = sScale + PMAXC;
@@ -174,11 +179,24 @@ __global__ __launch_bounds__(256) void k_conv_patch(
   const int tb = b % g.nbt; const int n = b / g.nbt;
   const int t0 = tb * g.bt, y0 = yb * g.by, x0 = xb * g.bx;
 
+  // strided data gradient: source coordinate o = (i + pad - tap) / stride when divisible.  The patch starts at
+  // po = floor((i0 + pad - (k-1)) / stride); base = i0 + pad - po*stride >= k-1 keeps every numerator >= 0.
+  int po_t = 0, po_h = 0, po_w = 0, base_t = 0, base_h = 0, base_w = 0;
+  if (STRIDED) {
+    const int nt_ = t0 + g.padt - (g.kt - 1), nh_ = y0 + g.padh - (g.kh - 1), nw_ = x0 + g.padw - (g.kw - 1);
+    po_t = nt_ >= 0 ? nt_ >> g.lt : -((-nt_ + g.dst_ - 1) >> g.lt);
+    po_h = nh_ >= 0 ? nh_ >> g.lh : -((-nh_ + g.dsh_ - 1) >> g.lh);
+    po_w = nw_ >= 0 ? nw_ >> g.lw : -((-nw_ + g.dsw_ - 1) >> g.lw);
+    base_t = t0 + g.padt - po_t * g.dst_; base_h = y0 + g.padh - po_h * g.dsh_; base_w = x0 + g.padw - po_w * g.dsw_;
+  }
+
   // ---- tables
   for (int p = t; p < g.P; p += 256) {
     const int ppt = p / g.pyx; const int r = p - ppt * g.pyx;
     const int ppy = r / g.px; const int ppx = r - ppy * g.px;
-    const int st = t0 * g.st + g.org_t + ppt, sy = y0 * g.sh + g.org_h + ppy, sx = x0 * g.sw + g.org_w + ppx;
+    int st, sy, sx;
+    if (STRIDED) { st = po_t + ppt; sy = po_h + ppy; sx = po_w + ppx; }
+    else { st = t0 * g.st + g.org_t + ppt; sy = y0 * g.sh + g.org_h + ppy; sx = x0 * g.sw + g.org_w + ppx; }
     const bool v = ((unsigned)st < (unsigned)g.Ts) && ((unsigned)sy < (unsigned)g.Hs) && ((unsigned)sx < (unsigned)g.Ws);
     sG[p] = v ? ((n * g.Ts + st) * g.Hs + sy) * g.Ws + sx : -1;
   }
@@ -186,18 +204,21 @@ __global__ __launch_bounds__(256) void k_conv_patch(
     const int rt = t / g.byx; const int r = t - rt * g.byx;
     const int ry = r / g.bx; const int rx = r - ry * g.bx;
     const bool v = (rt < g.bt) && (t0 + rt < g.Td) && (y0 + ry < g.Hd) && (x0 + rx < g.Wd);
-    int2 ri;
+    int4 ri;
     ri.x = v ? ((rt * g.st * g.py + ry * g.sh) * g.px + rx * g.sw) * g.ppitch : 0;
     ri.y = v ? ((n * g.Td + t0 + rt) * g.Hd + y0 + ry) * g.Wd + x0 + rx : -1;
+    ri.z = v ? ((base_t + rt) | ((base_h + ry) << 8) | ((base_w + rx) << 16)) : -1;
+    ri.w = 0;
     sR[t] = ri;
   }
   for (int q = t; q < g.nstages * 8; q += 256) {
-    int ko = 0;
+    int ko = STRIDED ? -1 : 0;              // strided: -1 marks a K-padding chunk (reads the zero pixel)
     if (q < g.Kc8) {
       const int tap = q / g.C8; const int c8 = q - tap * g.C8;
       const int dt = tap / g.khw; const int r = tap - dt * g.khw;
       const int dy = r / g.kw; const int dx = r - dy * g.kw;
-      ko = ((dt * g.py + dy) * g.px + dx) * g.ppitch + c8 * 16;
+      if (STRIDED) ko = dt | (dy << 8) | (dx << 16) | (c8 << 24);
+      else ko = ((dt * g.py + dy) * g.px + dx) * g.ppitch + c8 * 16;
     }
     sK[q] = ko;
   }
@@ -222,9 +243,23 @@ __global__ __launch_bounds__(256) void k_conv_patch(
 
   // ---- stage the patch: global 32 B per lane -> (BN+act) -> split -> 16 B hi + 16 B lo
   stage_image<F16>(src, g.Cps, 0, g.Cps >> 2, sG, g.P, g.C8, g.magicC8, sP, g.ppitch, g.lo_off, prologue, sScale, sShift, pslope, t);
+  if (STRIDED) {
+    for (int i = t * 16; i < g.ppitch; i += 256 * 16) {
+      *(uint4*)(sP + g.zero_off + i) = make_uint4(0, 0, 0, 0);
+      *(uint4*)(sP + g.lo_off + g.zero_off + i) = make_uint4(0, 0, 0, 0);
+    }
+  }
 
   // per-lane row offsets of this wave's two 16-row slabs
   const int rp0 = sR[wave * 32 + li].x, rp1 = sR[wave * 32 + 16 + li].x;
+  const int rc0 = sR[wave * 32 + li].z, rc1 = sR[wave * 32 + 16 + li].z;     // packed numerators (strided dgrad)
+  auto strided_off = [&](int rc, int tc) -> int {
+    if (rc < 0 || tc < 0) return g.zero_off;
+    const int pk = rc - (tc & 0xffffff);
+    const int ct = (pk & 0xff) >> g.lt, cy = ((pk >> 8) & 0xff) >> g.lh, cx = ((pk >> 16) & 0xff) >> g.lw;
+    const bool ok = ((pk & g.oddmask) == 0) && ct < g.pt && cy < g.py && cx < g.px;
+    return ok ? ((ct * g.py + cy) * g.px + cx) * g.ppitch + ((tc >> 24) & 0xff) * 16 : g.zero_off;
+  };
 
   f32x4 acc[2][PNREP];
 #pragma unroll
@@ -247,8 +282,10 @@ __global__ __launch_bounds__(256) void k_conv_patch(
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int ko = sK[kb * 8 + s * 4 + lg];
-      const uint4 ah0 = *(const uint4*)(sP + rp0 + ko), al0 = *(const uint4*)(sP + g.lo_off + rp0 + ko);
-      const uint4 ah1 = *(const uint4*)(sP + rp1 + ko), al1 = *(const uint4*)(sP + g.lo_off + rp1 + ko);
+      const int o0 = STRIDED ? strided_off(rc0, ko) : rp0 + ko;
+      const int o1 = STRIDED ? strided_off(rc1, ko) : rp1 + ko;
+      const uint4 ah0 = *(const uint4*)(sP + o0), al0 = *(const uint4*)(sP + g.lo_off + o0);
+      const uint4 ah1 = *(const uint4*)(sP + o1), al1 = *(const uint4*)(sP + g.lo_off + o1);
 #pragma unroll
       for (int j = 0; j < PNREP; ++j) {
         if (j < nrep) {
@@ -337,7 +374,8 @@ __global__ void k_pack_weights_x3(const float* __restrict__ w, int Cout, int Cin
   float v = 0.f;
   if (tap < taps) {
     if (mode == 0) { if (n < Cout && ch < Cin) v = w[((size_t)n * Cin + ch) * taps + tap]; }
-    else { if (n < Cin && ch < Cout) v = w[((size_t)ch * Cin + n) * taps + (taps - 1 - tap)]; }
+    else if (mode == 1) { if (n < Cin && ch < Cout) v = w[((size_t)ch * Cin + n) * taps + (taps - 1 - tap)]; }
+    else { if (n < Cin && ch < Cout) v = w[((size_t)ch * Cin + n) * taps + tap]; }
   }
   const size_t o_hi = ((size_t)(kb * 2 + 0) * N16 + n) * 64 + e64;
   const size_t o_lo = ((size_t)(kb * 2 + 1) * N16 + n) * 64 + e64;
@@ -364,59 +402,94 @@ static int pitch_for(int C8) {          // smallest 16*(4m+2) >= 16*C8
 }
 
 // Choose the output box (bt,by,bx), <= 128 pixels, minimising (boxes) x (MFMA rows + weighted patch pixels).
-static void choose_box(int T, int H, int W, int kt, int kh, int kw, int st, int sh, int sw, int* bt, int* by, int* bx) {
+// Choose the output box (bt,by,bx), <= 128 pixels, minimising (boxes) x (MFMA rows + weighted patch pixels) subject
+// to the LDS budget: `maxP` patch pixels at most, and a 25% penalty once the patch exceeds `softP` pixels (the size
+// up to which two workgroups still fit on one CU).  dgrad_s > 1: patch of a strided data gradient (source shrinks).
+static bool choose_box(int T, int H, int W, int kt, int kh, int kw, int st, int sh, int sw, int dgrad, int maxP, int softP,
+                       int* bt, int* by, int* bx) {
   double best = 1e300;
+  bool found = false;
+  auto pdim = [&](int b, int k, int s) { return dgrad ? (b + k - 2) / s + 2 : (b - 1) * s + k; };
   for (int t = 1; t <= T && t <= 32; ++t) {
     for (int x = 1; x <= 128; x *= 2) {
       const int xe = x >= W ? W : x;     // powers of two, and the full width
       int ymax = PM / (t * xe);
-      if (ymax < 1) continue;
-      if (ymax > H) ymax = H;
-      for (int y = ymax; y >= 1 && y >= ymax - 1; --y) {
-        const double boxes = (double)md_cdiv(T, t) * md_cdiv(H, y) * md_cdiv(W, xe);
-        const double patch = (double)((t - 1) * st + kt) * ((y - 1) * sh + kh) * ((xe - 1) * sw + kw);
-        const double cost = boxes * (PM + 0.6 * patch);
-        if (cost < best) { best = cost; *bt = t; *by = y; *bx = xe; }
+      if (ymax >= 1) {
+        if (ymax > H) ymax = H;
+        for (int y = ymax; y >= 1; y = (y > 4 ? y / 2 : y - 1)) {
+          const double boxes = (double)md_cdiv(T, t) * md_cdiv(H, y) * md_cdiv(W, xe);
+          const long long patch = (long long)pdim(t, kt, st) * pdim(y, kh, sh) * pdim(xe, kw, sw);
+          if (patch > maxP) continue;
+          double cost = boxes * (PM + 0.6 * (double)patch);
+          if (patch > softP) cost *= 1.25;
+          if (cost < best) { best = cost; *bt = t; *by = y; *bx = xe; found = true; }
+        }
       }
       if (x >= W) break;
     }
   }
+  return found;
 }
 
+static int ilog2_exact(int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; }
+
 static bool patch_build(const MdConvDesc* d, int dgrad, PGeom* out, size_t* lds_bytes) {
-  if (dgrad && (d->st != 1 || d->sh != 1 || d->sw != 1)) return false;
   PGeom g;
+  const bool sdg = dgrad && (d->st != 1 || d->sh != 1 || d->sw != 1);      // strided data gradient
+  g.strided = sdg ? 1 : 0;
+  if (sdg && (ilog2_exact(d->st) < 0 || ilog2_exact(d->sh) < 0 || ilog2_exact(d->sw) < 0)) return false;
   g.st = dgrad ? 1 : d->st; g.sh = dgrad ? 1 : d->sh; g.sw = dgrad ? 1 : d->sw;
+  g.dst_ = d->st; g.dsh_ = d->sh; g.dsw_ = d->sw;
+  g.lt = sdg ? ilog2_exact(d->st) : 0; g.lh = sdg ? ilog2_exact(d->sh) : 0; g.lw = sdg ? ilog2_exact(d->sw) : 0;
+  g.oddmask = (g.lt ? ((1 << g.lt) - 1) : 0) | ((g.lh ? ((1 << g.lh) - 1) : 0) << 8) | ((g.lw ? ((1 << g.lw) - 1) : 0) << 16);
+  g.kt = d->kt; g.padt = d->pt; g.padh = d->ph; g.padw = d->pw;
   const int cs = dgrad ? d->Cout : d->Cin, cd = dgrad ? d->Cin : d->Cout;
   g.Ts = dgrad ? d->To : d->Ti; g.Hs = dgrad ? d->Ho : d->Hi; g.Ws = dgrad ? d->Wo : d->Wi; g.Cps = md_cpad(cs);
   g.Td = dgrad ? d->Ti : d->To; g.Hd = dgrad ? d->Hi : d->Ho; g.Wd = dgrad ? d->Wi : d->Wo; g.Cpd = md_cpad(cd);
   g.kh = d->kh; g.kw = d->kw; g.khw = d->kh * d->kw; g.taps = d->kt * g.khw;
   if (!dgrad) { g.org_t = -d->pt; g.org_h = -d->ph; g.org_w = -d->pw; }
   else { g.org_t = d->pt - (d->kt - 1); g.org_h = d->ph - (d->kh - 1); g.org_w = d->pw - (d->kw - 1); }
-  choose_box(g.Td, g.Hd, g.Wd, d->kt, d->kh, d->kw, g.st, g.sh, g.sw, &g.bt, &g.by, &g.bx);
-  g.byx = g.by * g.bx;
-  g.nbt = md_cdiv(g.Td, g.bt); g.nby = md_cdiv(g.Hd, g.by); g.nbx = md_cdiv(g.Wd, g.bx);
-  g.pt = (g.bt - 1) * g.st + d->kt; g.py = (g.by - 1) * g.sh + d->kh; g.px = (g.bx - 1) * g.sw + d->kw;
-  g.pyx = g.py * g.px; g.P = g.pt * g.pyx;
   g.C8 = (g.Cps + 7) / 8;
   g.ppitch = pitch_for(g.C8);
-  g.lo_off = (g.P * g.ppitch + 15) & ~15;
   g.Kc8 = g.taps * g.C8;
   g.nstages = md_cdiv(g.Kc8, 8);
   g.N16 = md_round_up(cd, 16);
   g.magicC8 = g.C8 == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)g.C8) + 1u;
-  if ((long long)g.P * g.C8 >= 65536 || g.Cps > PMAXC) return false;
+  if (g.Cps > PMAXC) return false;
+  const int nchunks_ = md_cdiv(g.N16, PNREP * 16);
+  const int npb_ = md_round_up(md_cdiv(g.N16, nchunks_), 16);
+  // LDS: everything but the patch
+  const size_t fixed = (size_t)2 * npb_ * PB_PITCH + (size_t)g.nstages * 8 * 4 + (size_t)PM * 16 + 2 * PMAXC * 4 + 1024;
+  const size_t cap = 160 * 1024;
+  if (fixed + 4096 > cap) return false;
+  const long long per_px = (long long)2 * g.ppitch + 4;
+  long long maxP = (long long)(cap - fixed) / per_px - 2;
+  long long softP = (long long)(cap / 2 - fixed) / per_px - 2;
+  const long long idx_cap = 65535 / g.C8;              // item index must stay below 2^16 for the magic division
+  if (maxP > idx_cap) maxP = idx_cap;
+  if (softP < 1) softP = 1;
+  if (maxP < 1) return false;
+  if (!choose_box(g.Td, g.Hd, g.Wd, d->kt, d->kh, d->kw, sdg ? d->st : g.st, sdg ? d->sh : g.sh, sdg ? d->sw : g.sw, sdg,
+                  (int)maxP, (int)softP, &g.bt, &g.by, &g.bx)) return false;
+  g.byx = g.by * g.bx;
+  g.nbt = md_cdiv(g.Td, g.bt); g.nby = md_cdiv(g.Hd, g.by); g.nbx = md_cdiv(g.Wd, g.bx);
+  if (!sdg) {
+    g.pt = (g.bt - 1) * g.st + d->kt; g.py = (g.by - 1) * g.sh + d->kh; g.px = (g.bx - 1) * g.sw + d->kw;
+  } else {
+    g.pt = (g.bt + d->kt - 2) / d->st + 2; g.py = (g.by + d->kh - 2) / d->sh + 2; g.px = (g.bx + d->kw - 2) / d->sw + 2;
+  }
+  g.pyx = g.py * g.px; g.P = g.pt * g.pyx;
+  g.zero_off = g.P * g.ppitch;                          // one all-zero pixel behind the patch (invalid taps read it)
+  g.lo_off = ((g.P + 1) * g.ppitch + 15) & ~15;
   size_t off = (size_t)2 * g.lo_off;
   const size_t red = (size_t)4 * 2 * PNREP * 16 * 4;      // epilogue reduction scratch aliases the patch
   if (off < red) off = red;
-  const int nchunks_ = md_cdiv(g.N16, PNREP * 16);
-  const int npb_ = md_round_up(md_cdiv(g.N16, nchunks_), 16);
   g.off_b = (int)off; off += (size_t)2 * npb_ * PB_PITCH;
   g.off_koffs = (int)off; off += (size_t)g.nstages * 8 * 4;
-  g.off_rows = (int)off; off += (size_t)PM * 8;
+  g.off_rows = (int)off; off += (size_t)PM * 16;
   g.off_pixg = (int)off; off += (size_t)((g.P * 4 + 15) & ~15);
   g.off_scale = (int)off; off += (size_t)2 * PMAXC * 4;
-  if (off > 160 * 1024) return false;
+  if (off > cap) return false;
   *out = g; *lds_bytes = off;
   return true;
 }
@@ -459,7 +532,7 @@ int patch_blocks(const PatchPlan* p) { return p->N * p->g.nbt * p->g.nby * p->g.
 int patch_pack(const MdConvDesc* d, int dgrad, const PatchPlan* p, const float* w, float* out, hipStream_t s) {
   const PGeom& g = p->g;
   const int total = g.nstages * g.N16 * 64;
-  hipLaunchKernelGGL(k_pack_weights_x3, dim3(md_cdiv(total, 256)), dim3(256), 0, s, w, d->Cout, d->Cin, g.taps, dgrad, g.C8,
+  hipLaunchKernelGGL(k_pack_weights_x3, dim3(md_cdiv(total, 256)), dim3(256), 0, s, w, d->Cout, d->Cin, g.taps, dgrad ? (g.strided ? 2 : 1) : 0, g.C8,
                      g.nstages, g.N16, (unsigned short*)out, dgrad ? 0 : 1);
   MD_CHECK_LAUNCH();
   return MD_OK;
@@ -473,17 +546,21 @@ int patch_launch(const PatchPlan* p, const float* src, const float* ps, const fl
   dim3 grid(patch_blocks(p), md_cdiv(g.N16, npb));
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_conv_patch<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_conv_patch<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)k_conv_patch<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_conv_patch<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_conv_patch<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return MD_ERR_LAUNCH;
     attr_set = true;
   }
-  if (p->dgrad)
-    hipLaunchKernelGGL(k_conv_patch<false>, grid, dim3(256), p->lds, s, g, src, ps, psh, slope, (const uint4*)wp, dst, stat,
-                       accumulate, npb);
+  if (!p->dgrad)
+    hipLaunchKernelGGL((k_conv_patch<true, false>), grid, dim3(256), p->lds, s, g, src, ps, psh, slope, (const uint4*)wp, dst,
+                       stat, accumulate, npb);
+  else if (!g.strided)
+    hipLaunchKernelGGL((k_conv_patch<false, false>), grid, dim3(256), p->lds, s, g, src, ps, psh, slope, (const uint4*)wp, dst,
+                       stat, accumulate, npb);
   else
-    hipLaunchKernelGGL(k_conv_patch<true>, grid, dim3(256), p->lds, s, g, src, ps, psh, slope, (const uint4*)wp, dst, stat,
-                       accumulate, npb);
+    hipLaunchKernelGGL((k_conv_patch<false, true>), grid, dim3(256), p->lds, s, g, src, ps, psh, slope, (const uint4*)wp, dst,
+                       stat, accumulate, npb);
   MD_CHECK_LAUNCH();
   return MD_OK;
 }
@@ -695,15 +772,9 @@ static bool wgrad_build(const MdConvDesc* d, WGeom* out, size_t* lds_bytes, int*
   g.To = d->To; g.Ho = d->Ho; g.Wo = d->Wo; g.Cpo = md_cpad(d->Cout);
   g.kh = d->kh; g.kw = d->kw; g.khw = d->kh * d->kw; g.taps = d->kt * g.khw;
   g.org_t = -d->pt; g.org_h = -d->ph; g.org_w = -d->pw;
-  choose_box(g.To, g.Ho, g.Wo, d->kt, d->kh, d->kw, g.st, g.sh, g.sw, &g.bt, &g.by, &g.bx);
-  g.byx = g.by * g.bx;
-  g.nbt = md_cdiv(g.To, g.bt); g.nby = md_cdiv(g.Ho, g.by); g.nbx = md_cdiv(g.Wo, g.bx);
-  g.pt = (g.bt - 1) * g.st + d->kt; g.py = (g.by - 1) * g.sh + d->kh; g.px = (g.bx - 1) * g.sw + d->kw;
-  g.pyx = g.py * g.px; g.P = g.pt * g.pyx;
   g.KT = md_cdiv(d->Cin, 16); g.nkt = g.taps * g.KT;
   g.C8i = 2 * g.KT;
   g.ppitch = pitch_for(g.C8i);
-  g.lo_off = (g.P * g.ppitch + 15) & ~15;
   g.N16 = md_round_up(d->Cout, 16);
   const int NT = g.N16 / 16;
   g.nng = md_cdiv(NT, WNR); g.nrep = md_cdiv(NT, g.nng);
@@ -714,8 +785,25 @@ static bool wgrad_build(const MdConvDesc* d, WGeom* out, size_t* lds_bytes, int*
   g.ylo_off = PM * g.ypitch;
   g.magicC8 = g.C8i == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)g.C8i) + 1u;
   g.magicNC = g.NC == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)g.NC) + 1u;
+  if (g.Cpi > PMAXC) return false;
+  const size_t cap = 160 * 1024;
+  const size_t fixed = (size_t)2 * g.ylo_off + (size_t)PM * 8 + (size_t)PM * 4 + 2 * PMAXC * 4 + 1024;
+  if (fixed + 4096 > cap) return false;
+  const long long per_px = (long long)2 * g.ppitch + 4;
+  long long maxP = (long long)(cap - fixed) / per_px - 2;
+  long long softP = (long long)(cap / 2 - fixed) / per_px - 2;
+  const long long idx_cap = 65535 / g.C8i;
+  if (maxP > idx_cap) maxP = idx_cap;
+  if (softP < 1) softP = 1;
+  if (maxP < 1) return false;
+  if (!choose_box(g.To, g.Ho, g.Wo, d->kt, d->kh, d->kw, g.st, g.sh, g.sw, 0, (int)maxP, (int)softP, &g.bt, &g.by, &g.bx))
+    return false;
+  g.byx = g.by * g.bx;
+  g.nbt = md_cdiv(g.To, g.bt); g.nby = md_cdiv(g.Ho, g.by); g.nbx = md_cdiv(g.Wo, g.bx);
+  g.pt = (g.bt - 1) * g.st + d->kt; g.py = (g.by - 1) * g.sh + d->kh; g.px = (g.bx - 1) * g.sw + d->kw;
+  g.pyx = g.py * g.px; g.P = g.pt * g.pyx;
+  g.lo_off = (g.P * g.ppitch + 15) & ~15;
   g.nboxes = d->N * g.nbt * g.nby * g.nbx;
-  if ((long long)g.P * g.C8i >= 65536 || g.Cpi > PMAXC) return false;
   // enough workgroups to fill the chip, few enough that the slabs stay small
   int want = md_cdiv(512, g.nkg * g.nng);
   if (want > g.nboxes) want = g.nboxes;
@@ -728,7 +816,7 @@ static bool wgrad_build(const MdConvDesc* d, WGeom* out, size_t* lds_bytes, int*
   g.off_pixg = (int)off; off += (size_t)(((g.P + 3) & ~3) + PM) * 4;
   off = (off + 15) & ~(size_t)15;
   g.off_scale = (int)off; off += (size_t)2 * PMAXC * 4;
-  if (off > 160 * 1024) return false;
+  if (off > cap) return false;
   *out = g; *lds_bytes = off;
   return true;
 }

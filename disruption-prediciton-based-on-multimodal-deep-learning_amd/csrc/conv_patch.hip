@@ -150,7 +150,7 @@ __device__ __forceinline__ f32x4 mma(uint4 a, uint4 b, f32x4 c) {
 
 // F16 = true: forward convolution, operands split into fp16 halves (activations/weights are O(1) quantities);
 // F16 = false: data gradient, operands split into bf16 halves (gradients need bf16's exponent range).
-template <bool F16, bool STRIDED>
+template <bool F16, bool STRIDED, int NREP>
 __global__ __launch_bounds__(256) void k_conv_patch(
     PGeom g, const float* __restrict__ src, const float* __restrict__ pscale, const float* __restrict__ pshift,
     float pslope, const uint4* __restrict__ wp, float* __restrict__ dst, float* __restrict__ stat_partial,
@@ -169,8 +169,9 @@ __global__ __launch_bounds__(256) void k_conv_patch(
   const int li = lane & 15, lg = lane >> 4;
   const int n0 = blockIdx.y * n_per_blk;
   const int ncols = min(n_per_blk, g.N16 - n0);
-  const int nrep = ncols >> 4;
   const bool prologue = pscale != nullptr;
+  const int dbg = accumulate >> 8;      // timing experiments (MD_DBG): 1 skip patch loads, 2 skip MFMA loop, 4 skip stores
+  accumulate &= 1;
 
   // ---- which box
   int b = blockIdx.x;
@@ -242,7 +243,8 @@ __global__ __launch_bounds__(256) void k_conv_patch(
   __syncthreads();
 
   // ---- stage the patch: global 32 B per lane -> (BN+act) -> split -> 16 B hi + 16 B lo
-  stage_image<F16>(src, g.Cps, 0, g.Cps >> 2, sG, g.P, g.C8, g.magicC8, sP, g.ppitch, g.lo_off, prologue, sScale, sShift, pslope, t);
+  if (!(dbg & 1))
+    stage_image<F16>(src, g.Cps, 0, g.Cps >> 2, sG, g.P, g.C8, g.magicC8, sP, g.ppitch, g.lo_off, prologue, sScale, sShift, pslope, t);
   if (STRIDED) {
     for (int i = t * 16; i < g.ppitch; i += 256 * 16) {
       *(uint4*)(sP + g.zero_off + i) = make_uint4(0, 0, 0, 0);
@@ -261,14 +263,14 @@ __global__ __launch_bounds__(256) void k_conv_patch(
     return ok ? ((ct * g.py + cy) * g.px + cx) * g.ppitch + ((tc >> 24) & 0xff) * 16 : g.zero_off;
   };
 
-  f32x4 acc[2][PNREP];
+  f32x4 acc[2][NREP];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int j = 0; j < PNREP; ++j) acc[a][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NREP; ++j) acc[a][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int blo = n_per_blk * PB_PITCH;    // lo half of the B tile
-  for (int kb = 0; kb < g.nstages; ++kb) {
+  for (int kb = 0; kb < ((dbg & 2) ? 0 : g.nstages); ++kb) {
     __syncthreads();                       // patch staged (first iteration) / previous B tile consumed
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -287,8 +289,8 @@ __global__ __launch_bounds__(256) void k_conv_patch(
       const uint4 ah0 = *(const uint4*)(sP + o0), al0 = *(const uint4*)(sP + g.lo_off + o0);
       const uint4 ah1 = *(const uint4*)(sP + o1), al1 = *(const uint4*)(sP + g.lo_off + o1);
 #pragma unroll
-      for (int j = 0; j < PNREP; ++j) {
-        if (j < nrep) {
+      for (int j = 0; j < NREP; ++j) {
+        {
           const char* bp = sB + (j * 16 + li) * PB_PITCH + (s * 4 + lg) * 16;
           const uint4 bh = *(const uint4*)bp, bl = *(const uint4*)(bp + blo);
           // smallest terms first: lo*hi and hi*lo, then hi*hi
@@ -312,8 +314,8 @@ __global__ __launch_bounds__(256) void k_conv_patch(
   __syncthreads();
   float* red = (float*)sP;   // [4 waves][2][PNREP*16]
 #pragma unroll
-  for (int j = 0; j < PNREP; ++j) {
-    if (j < nrep) {
+  for (int j = 0; j < NREP; ++j) {
+    {
       const int col = n0 + j * 16 + li;
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(256) void k_conv_patch(
           if (gi >= 0) {
             float v = acc[a][j][r];
             s1 += v; s2 = fmaf(v, v, s2);
-            if (col < g.Cpd) {
+            if (col < g.Cpd && !(dbg & 4)) {
               float* p = dst + (size_t)gi * g.Cpd + col;
               if (accumulate) v += *p;
               *p = v;
@@ -544,23 +546,35 @@ int patch_launch(const PatchPlan* p, const float* src, const float* ps, const fl
   const int nchunks = md_cdiv(g.N16, PNREP * 16);
   const int npb = md_round_up(md_cdiv(g.N16, nchunks), 16);
   dim3 grid(patch_blocks(p), md_cdiv(g.N16, npb));
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_conv_patch<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_conv_patch<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_conv_patch<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return MD_ERR_LAUNCH;
-    attr_set = true;
+  static const int dbg = getenv("MD_DBG") ? atoi(getenv("MD_DBG")) : 0;
+  accumulate = (accumulate & 1) | (dbg << 8);
+  const int nrep = npb / 16;
+#define LAUNCH_PATCH(F16_, STR_, NR_)                                                                                   \
+  do {                                                                                                                  \
+    static bool set_ = false;                                                                                           \
+    if (!set_) {                                                                                                        \
+      if (hipFuncSetAttribute((const void*)k_conv_patch<F16_, STR_, NR_>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                              160 * 1024) != hipSuccess) return MD_ERR_LAUNCH;                                          \
+      set_ = true;                                                                                                      \
+    }                                                                                                                   \
+    hipLaunchKernelGGL((k_conv_patch<F16_, STR_, NR_>), grid, dim3(256), p->lds, s, g, src, ps, psh, slope,             \
+                       (const uint4*)wp, dst, stat, accumulate, npb);                                                   \
+  } while (0)
+#define LAUNCH_PATCH_NR(F16_, STR_)                                                                                     \
+  switch (nrep) {                                                                                                       \
+    case 1: LAUNCH_PATCH(F16_, STR_, 1); break;                                                                         \
+    case 2: LAUNCH_PATCH(F16_, STR_, 2); break;                                                                         \
+    case 3: LAUNCH_PATCH(F16_, STR_, 3); break;                                                                         \
+    case 4: LAUNCH_PATCH(F16_, STR_, 4); break;                                                                         \
+    case 5: LAUNCH_PATCH(F16_, STR_, 5); break;                                                                         \
+    case 6: LAUNCH_PATCH(F16_, STR_, 6); break;                                                                         \
+    case 7: LAUNCH_PATCH(F16_, STR_, 7); break;                                                                         \
+    case 8: LAUNCH_PATCH(F16_, STR_, 8); break;                                                                         \
+    default: LAUNCH_PATCH(F16_, STR_, 9); break;                                                                        \
   }
-  if (!p->dgrad)
-    hipLaunchKernelGGL((k_conv_patch<true, false>), grid, dim3(256), p->lds, s, g, src, ps, psh, slope, (const uint4*)wp, dst,
-                       stat, accumulate, npb);
-  else if (!g.strided)
-    hipLaunchKernelGGL((k_conv_patch<false, false>), grid, dim3(256), p->lds, s, g, src, ps, psh, slope, (const uint4*)wp, dst,
-                       stat, accumulate, npb);
-  else
-    hipLaunchKernelGGL((k_conv_patch<false, true>), grid, dim3(256), p->lds, s, g, src, ps, psh, slope, (const uint4*)wp, dst,
-                       stat, accumulate, npb);
+  if (!p->dgrad) { LAUNCH_PATCH_NR(true, false); }
+  else if (!g.strided) { LAUNCH_PATCH_NR(false, false); }
+  else { LAUNCH_PATCH_NR(false, true); }
   MD_CHECK_LAUNCH();
   return MD_OK;
 }
@@ -606,9 +620,10 @@ __device__ __forceinline__ bf16x8 tr_read2(const char* p0, const char* p1) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
+template <int KTW, int NREP>
 __global__ __launch_bounds__(256) void k_wgrad_patch(
     WGeom g, const float* __restrict__ src, const float* __restrict__ pscale, const float* __restrict__ pshift,
-    float pslope, const float* __restrict__ dy, float* __restrict__ slab) {
+    float pslope, const float* __restrict__ dy, float* __restrict__ slab, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
   char* sP = sm;
   char* sY = sm + g.off_y;
@@ -629,19 +644,19 @@ __global__ __launch_bounds__(256) void k_wgrad_patch(
   const bool prologue = pscale != nullptr;
   if (prologue) for (int c = t; c < g.Cpi; c += 256) { sScale[c] = pscale[c]; sShift[c] = pshift[c]; }
 
-  f32x4 acc[WKT][WNR];
+  f32x4 acc[KTW][NREP];
 #pragma unroll
-  for (int a = 0; a < WKT; ++a)
+  for (int a = 0; a < KTW; ++a)
 #pragma unroll
-    for (int j = 0; j < WNR; ++j) acc[a][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NREP; ++j) acc[a][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // byte offset inside the X patch of each of this wave's k-tiles: tap pixel offset + 32 B per 16 channels
-  int koff[WKT];
+  int koff[KTW];
 #pragma unroll
-  for (int a = 0; a < WKT; ++a) {
+  for (int a = 0; a < KTW; ++a) {
     const int kt = kt0 + a;
     int o = 0;
-    if (a < g.ktw && kt < g.nkt) {
+    if (kt < g.nkt) {
       const int tap = kt / g.KT; const int c16 = kt - tap * g.KT;
       const int dt = tap / g.khw; const int r = tap - dt * g.khw;
       const int dyy = r / g.kw; const int dxx = r - dyy * g.kw;
@@ -678,36 +693,33 @@ __global__ __launch_bounds__(256) void k_wgrad_patch(
       sGY[t] = ri.y;
     }
     __syncthreads();
-    stage_image<false>(src, g.Cpi, 0, g.Cpi >> 2, sG, g.P, g.C8i, g.magicC8, sP, g.ppitch, g.lo_off, prologue, sScale, sShift,
+    if (!(dbg & 1)) stage_image<false>(src, g.Cpi, 0, g.Cpi >> 2, sG, g.P, g.C8i, g.magicC8, sP, g.ppitch, g.lo_off, prologue, sScale, sShift,
                 pslope, t);
-    stage_image<false>(dy, g.Cpo, n0, ycv4, sGY, PM, g.NC, g.magicNC, sY, g.ypitch, g.ylo_off, false, nullptr, nullptr, 1.f, t);
+    if (!(dbg & 2)) stage_image<false>(dy, g.Cpo, n0, ycv4, sGY, PM, g.NC, g.magicNC, sY, g.ypitch, g.ylo_off, false, nullptr, nullptr, 1.f, t);
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int r0 = s * 32 + lg * 8 + lq;                 // this lane's address row of the first 4-pixel block
-      const int xa = sR[r0].x + lp * 8, xb2 = sR[r0 + 4].x + lp * 8;
-      const int ya = r0 * g.ypitch + lp * 8, yb2 = (r0 + 4) * g.ypitch + lp * 8;
-      bf16x8 bh[WNR], bl[WNR];
+    for (int s = 0; s < ((dbg & 4) ? 0 : 4); ++s) {
+      // The MFMA's 32 reduction slots of this step are pixels; lane group lg takes pixels {4lg..4lg+3} and
+      // {16+4lg..16+4lg+3} of the step (any assignment works as long as A and B agree).  A half-wave's first read
+      // then covers 8 CONSECUTIVE pixels: with the odd-multiple-of-32-byte pixel pitch that is conflict free.
+      const int r0 = s * 32 + lg * 4 + lq;
+      const int xa = sR[r0].x + lp * 8, xb2 = sR[r0 + 16].x + lp * 8;
+      const int ya = r0 * g.ypitch + lp * 8, yb2 = (r0 + 16) * g.ypitch + lp * 8;
+      bf16x8 bh[NREP], bl[NREP];
 #pragma unroll
-      for (int j = 0; j < WNR; ++j) {
-        if (j < g.nrep) {
-          bh[j] = tr_read2(sY + ya + j * 32, sY + yb2 + j * 32);
-          bl[j] = tr_read2(sY + g.ylo_off + ya + j * 32, sY + g.ylo_off + yb2 + j * 32);
-        }
+      for (int j = 0; j < NREP; ++j) {
+        bh[j] = tr_read2(sY + ya + j * 32, sY + yb2 + j * 32);
+        bl[j] = tr_read2(sY + g.ylo_off + ya + j * 32, sY + g.ylo_off + yb2 + j * 32);
       }
 #pragma unroll
-      for (int a = 0; a < WKT; ++a) {
-        if (a < g.ktw) {
-          const bf16x8 ah = tr_read2(sP + xa + koff[a], sP + xb2 + koff[a]);
-          const bf16x8 al = tr_read2(sP + g.lo_off + xa + koff[a], sP + g.lo_off + xb2 + koff[a]);
+      for (int a = 0; a < KTW; ++a) {
+        const bf16x8 ah = tr_read2(sP + xa + koff[a], sP + xb2 + koff[a]);
+        const bf16x8 al = tr_read2(sP + g.lo_off + xa + koff[a], sP + g.lo_off + xb2 + koff[a]);
 #pragma unroll
-          for (int j = 0; j < WNR; ++j) {
-            if (j < g.nrep) {
-              acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[a][j], 0, 0, 0);
-              acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[a][j], 0, 0, 0);
-              acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[a][j], 0, 0, 0);
-            }
-          }
+        for (int j = 0; j < NREP; ++j) {
+          acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[a][j], 0, 0, 0);
+          acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[a][j], 0, 0, 0);
+          acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[a][j], 0, 0, 0);
         }
       }
     }
@@ -716,12 +728,12 @@ __global__ __launch_bounds__(256) void k_wgrad_patch(
   // ---- slab[slice][k16 row][N16]: D rows = k index (4*lg + reg), cols = cout (li)
   float* out = slab + (size_t)blockIdx.x * g.nkt * 16 * g.N16;
 #pragma unroll
-  for (int a = 0; a < WKT; ++a) {
+  for (int a = 0; a < KTW; ++a) {
     const int kt = kt0 + a;
-    if (a < g.ktw && kt < g.nkt) {
+    if (kt < g.nkt) {
 #pragma unroll
-      for (int j = 0; j < WNR; ++j) {
-        if (j < g.nrep) {
+      for (int j = 0; j < NREP; ++j) {
+        {
           const int col = n0 + j * 16 + li;
           if (col < g.N16) {
 #pragma unroll
@@ -778,7 +790,7 @@ static bool wgrad_build(const MdConvDesc* d, WGeom* out, size_t* lds_bytes, int*
   g.N16 = md_round_up(d->Cout, 16);
   const int NT = g.N16 / 16;
   g.nng = md_cdiv(NT, WNR); g.nrep = md_cdiv(NT, g.nng);
-  g.ktw = md_cdiv(g.nkt, 4); if (g.ktw > WKT) g.ktw = WKT;
+  g.ktw = md_cdiv(g.nkt, 4) <= 3 ? 3 : WKT;            // instantiated: 3 or 5 k-tiles per wave
   g.nkg = md_cdiv(g.nkt, 4 * g.ktw);
   g.NC = 2 * g.nrep;
   g.ypitch = pitch_for(g.NC);
@@ -844,14 +856,27 @@ size_t wgrad_patch_workspace_floats(const WgradPlan* p) { return (size_t)p->nsli
 int wgrad_patch_launch(const WgradPlan* p, const MdConvDesc* d, const float* src, const float* ps, const float* psh,
                        float slope, const float* dy, float* dw, float* slab, hipStream_t s) {
   const WGeom& g = p->g;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_wgrad_patch, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return MD_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static const int dbg = getenv("MD_DBG") ? atoi(getenv("MD_DBG")) : 0;
   dim3 grid(p->nslices, g.nkg * g.nng);
-  hipLaunchKernelGGL(k_wgrad_patch, grid, dim3(256), p->lds, s, g, src, ps, psh, slope, dy, slab);
+#define LAUNCH_WG(KT_, NR_)                                                                                             \
+  do {                                                                                                                  \
+    static bool set_ = false;                                                                                           \
+    if (!set_) {                                                                                                        \
+      if (hipFuncSetAttribute((const void*)k_wgrad_patch<KT_, NR_>, hipFuncAttributeMaxDynamicSharedMemorySize,         \
+                              160 * 1024) != hipSuccess) return MD_ERR_LAUNCH;                                          \
+      set_ = true;                                                                                                      \
+    }                                                                                                                   \
+    hipLaunchKernelGGL((k_wgrad_patch<KT_, NR_>), grid, dim3(256), p->lds, s, g, src, ps, psh, slope, dy, slab, dbg);   \
+  } while (0)
+#define LAUNCH_WG_NR(KT_)                                                                                               \
+  switch (g.nrep) {                                                                                                     \
+    case 1: LAUNCH_WG(KT_, 1); break;                                                                                   \
+    case 2: LAUNCH_WG(KT_, 2); break;                                                                                   \
+    case 3: LAUNCH_WG(KT_, 3); break;                                                                                   \
+    case 4: LAUNCH_WG(KT_, 4); break;                                                                                   \
+    default: LAUNCH_WG(KT_, 5); break;                                                                                  \
+  }
+  if (g.ktw == 3) { LAUNCH_WG_NR(3); } else { LAUNCH_WG_NR(5); }
   MD_CHECK_LAUNCH();
   const int total = g.nkt * 16 * g.N16;
   hipLaunchKernelGGL(k_wgrad_reduce, dim3(md_cdiv(total, 64)), dim3(256), 0, s, slab, p->nslices, g.nkt, g.KT, g.N16, d->Cout,

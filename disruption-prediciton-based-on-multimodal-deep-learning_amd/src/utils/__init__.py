@@ -1,0 +1,5 @@
+import os as _os
+
+_ref = _os.environ.get("MD_REFERENCE_SRC")
+if _ref and _os.path.isdir(_os.path.join(_ref, "utils")):
+    __path__.append(_os.path.join(_ref, "utils"))

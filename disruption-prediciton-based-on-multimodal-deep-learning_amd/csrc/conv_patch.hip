@@ -745,6 +745,217 @@ __global__ __launch_bounds__(256) void k_wgrad_patch(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Software-pipelined variant: the global loads of box i+1 (X patch and dY rows, up to 6+5 32-byte items per
+// thread) are issued into registers BEFORE the MFMA phase of box i and committed (BN-on-read, hi/lo split, LDS
+// write) after it, so HBM latency hides behind the matrix work.  One workgroup per CU is all the accumulator
+// budget allows for this kernel, so nothing else would overlap the loads.  All per-item index arithmetic that
+// does not depend on the box is done once.
+// ------------------------------------------------------------------------------------------------
+#define WPF_X 6
+#define WPF_Y 5
+template <int KTW, int NREP>
+__global__ __launch_bounds__(256) void k_wgrad_patch_pf(
+    WGeom g, const float* __restrict__ src, const float* __restrict__ pscale, const float* __restrict__ pshift,
+    float pslope, const float* __restrict__ dy, float* __restrict__ slab) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  char* sP = sm;
+  char* sY = sm + g.off_y;
+  int* sRx = (int*)(sm + g.off_rows);           // [PM] X patch byte offset of each output row (box independent)
+  float* sScale = (float*)(sm + g.off_scale);
+  float* sShift = sScale + PMAXC;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int lq = li >> 2, lp = li & 3;
+  const int kg = blockIdx.y / g.nng, ng = blockIdx.y - kg * g.nng;
+  const int n0 = ng * g.nrep * 16;
+  const int kt0 = (kg * 4 + wave) * g.ktw;
+  const bool prologue = pscale != nullptr;
+  if (prologue) for (int c = t; c < g.Cpi; c += 256) { sScale[c] = pscale[c]; sShift[c] = pshift[c]; }
+  if (t < PM) {
+    const int rt = t / g.byx; const int r = t - rt * g.byx;
+    const int ry = r / g.bx; const int rx = r - ry * g.bx;
+    sRx[t] = (rt < g.bt) ? ((rt * g.st * g.py + ry * g.sh) * g.px + rx * g.sw) * g.ppitch : 0;
+  }
+
+  f32x4 acc[KTW][NREP];
+#pragma unroll
+  for (int a = 0; a < KTW; ++a)
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) acc[a][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int koff[KTW];
+#pragma unroll
+  for (int a = 0; a < KTW; ++a) {
+    const int kt = kt0 + a;
+    int o = 0;
+    if (kt < g.nkt) {
+      const int tap = kt / g.KT; const int c16 = kt - tap * g.KT;
+      const int dt = tap / g.khw; const int r = tap - dt * g.khw;
+      const int dyy = r / g.kw; const int dxx = r - dyy * g.kw;
+      o = ((dt * g.py + dyy) * g.px + dxx) * g.ppitch + c16 * 32;
+    }
+    koff[a] = o;
+  }
+
+  // ---- box-independent decode of this thread's items
+  const int totX = g.P * g.C8i, totY = PM * g.NC;
+  const int xcv4 = g.Cpi >> 2;
+  const int ycv4 = max(0, min(g.NC * 2, (g.Cpo - n0) >> 2));
+  int xloc[WPF_X], xdst[WPF_X];      // packed (ppt | ppy<<6 | ppx<<15 | c8<<24), LDS byte offset (or -1: no item)
+  int yloc[WPF_Y], ydst[WPF_Y];      // packed (rt | ry<<6 | rx<<15 | c<<24)
+#pragma unroll
+  for (int u = 0; u < WPF_X; ++u) {
+    const int item = u * 256 + t;
+    xdst[u] = -1; xloc[u] = 0;
+    if (item < totX) {
+      const int pixel = g.magicC8 ? (int)__umulhi((unsigned)item, g.magicC8) : item;
+      const int c8 = item - pixel * g.C8i;
+      const int ppt = pixel / g.pyx; const int r = pixel - ppt * g.pyx;
+      const int ppy = r / g.px; const int ppx = r - ppy * g.px;
+      xloc[u] = ppt | (ppy << 6) | (ppx << 15) | (c8 << 24);
+      xdst[u] = pixel * g.ppitch + c8 * 16;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < WPF_Y; ++u) {
+    const int item = u * 256 + t;
+    ydst[u] = -1; yloc[u] = 0;
+    if (item < totY) {
+      const int row = g.magicNC ? (int)__umulhi((unsigned)item, g.magicNC) : item;
+      const int c = item - row * g.NC;
+      const int rt = row / g.byx; const int r = row - rt * g.byx;
+      const int ry = r / g.bx; const int rx = r - ry * g.bx;
+      yloc[u] = rt | (ry << 6) | (rx << 15) | (c << 24);
+      ydst[u] = (rt < g.bt) ? row * g.ypitch + c * 16 : -2;      // -2: row outside the box -> zeros
+    }
+  }
+
+  float4 xa_[WPF_X], xb_[WPF_X], ya_[WPF_Y], yb_[WPF_Y];
+  int xfl = 0, yfl = 0;       // per item 2 bits: bit0 = loaded (inside the tensor), bit1 = upper half is padding
+  auto issue = [&](int box) {
+    int b = box;
+    const int xb = b % g.nbx; b /= g.nbx;
+    const int yb = b % g.nby; b /= g.nby;
+    const int tb = b % g.nbt; const int n = b / g.nbt;
+    const int t0 = tb * g.bt, y0 = yb * g.by, x0 = xb * g.bx;
+    const int ot = t0 * g.st + g.org_t, oh = y0 * g.sh + g.org_h, ow = x0 * g.sw + g.org_w;
+    xfl = 0; yfl = 0;
+#pragma unroll
+    for (int u = 0; u < WPF_X; ++u) {
+      xa_[u] = make_float4(0.f, 0.f, 0.f, 0.f); xb_[u] = xa_[u];
+      if (xdst[u] >= 0) {
+        const int st = ot + (xloc[u] & 63), sy = oh + ((xloc[u] >> 6) & 511), sx = ow + ((xloc[u] >> 15) & 511);
+        const int c8 = (xloc[u] >> 24) & 255;
+        if (((unsigned)st < (unsigned)g.Ti) && ((unsigned)sy < (unsigned)g.Hi) && ((unsigned)sx < (unsigned)g.Wi) &&
+            c8 * 2 < xcv4) {
+          const float* s = src + ((size_t)((n * g.Ti + st) * g.Hi + sy) * g.Wi + sx) * g.Cpi + c8 * 8;
+          xa_[u] = *(const float4*)s;
+          xfl |= 1 << (2 * u);
+          if (c8 * 2 + 1 < xcv4) xb_[u] = *(const float4*)(s + 4); else xfl |= 2 << (2 * u);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < WPF_Y; ++u) {
+      ya_[u] = make_float4(0.f, 0.f, 0.f, 0.f); yb_[u] = ya_[u];
+      if (ydst[u] >= 0) {
+        const int ot_ = t0 + (yloc[u] & 63), oy_ = y0 + ((yloc[u] >> 6) & 511), ox_ = x0 + ((yloc[u] >> 15) & 511);
+        const int c = (yloc[u] >> 24) & 255;
+        if (ot_ < g.To && oy_ < g.Ho && ox_ < g.Wo && c * 2 < ycv4) {
+          const float* s = dy + ((size_t)((n * g.To + ot_) * g.Ho + oy_) * g.Wo + ox_) * g.Cpo + n0 + c * 8;
+          ya_[u] = *(const float4*)s;
+          yfl |= 1 << (2 * u);
+          if (c * 2 + 1 < ycv4) yb_[u] = *(const float4*)(s + 4);
+        }
+      }
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < WPF_X; ++u) {
+      if (xdst[u] >= 0) {
+        float v[8] = {xa_[u].x, xa_[u].y, xa_[u].z, xa_[u].w, xb_[u].x, xb_[u].y, xb_[u].z, xb_[u].w};
+        if (prologue && ((xfl >> (2 * u)) & 1)) {
+          const int c8 = (xloc[u] >> 24) & 255;
+          const float* sc = sScale + c8 * 8; const float* sh = sShift + c8 * 8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = md_leaky(fmaf(v[e], sc[e], sh[e]), pslope);
+          if ((xfl >> (2 * u)) & 2) { v[4] = v[5] = v[6] = v[7] = 0.f; }
+        }
+        uint4 hi, lo;
+        split8(v, hi, lo);
+        *(uint4*)(sP + xdst[u]) = hi;
+        *(uint4*)(sP + g.lo_off + xdst[u]) = lo;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < WPF_Y; ++u) {
+      if (ydst[u] != -1) {
+        const int item = u * 256 + t;
+        const int row = g.magicNC ? (int)__umulhi((unsigned)item, g.magicNC) : item;
+        const int off = row * g.ypitch + ((yloc[u] >> 24) & 255) * 16;
+        const float v[8] = {ya_[u].x, ya_[u].y, ya_[u].z, ya_[u].w, yb_[u].x, yb_[u].y, yb_[u].z, yb_[u].w};
+        uint4 hi, lo;
+        split8(v, hi, lo);
+        *(uint4*)(sY + off) = hi;
+        *(uint4*)(sY + g.ylo_off + off) = lo;
+      }
+    }
+  };
+
+  const int box_beg = blockIdx.x * g.boxes_per_wg;
+  const int box_end = min(g.nboxes, box_beg + g.boxes_per_wg);
+  if (box_beg < box_end) issue(box_beg);
+  for (int box = box_beg; box < box_end; ++box) {
+    __syncthreads();          // previous box fully consumed (first iteration: tables / scale in LDS)
+    commit();
+    __syncthreads();
+    if (box + 1 < box_end) issue(box + 1);      // in flight during the MFMA phase below
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int r0 = s * 32 + lg * 4 + lq;
+      const int xa = sRx[r0] + lp * 8, xb2 = sRx[r0 + 16] + lp * 8;
+      const int ya = r0 * g.ypitch + lp * 8, yb2 = (r0 + 16) * g.ypitch + lp * 8;
+      bf16x8 bh[NREP], bl[NREP];
+#pragma unroll
+      for (int j = 0; j < NREP; ++j) {
+        bh[j] = tr_read2(sY + ya + j * 32, sY + yb2 + j * 32);
+        bl[j] = tr_read2(sY + g.ylo_off + ya + j * 32, sY + g.ylo_off + yb2 + j * 32);
+      }
+#pragma unroll
+      for (int a = 0; a < KTW; ++a) {
+        const bf16x8 ah = tr_read2(sP + xa + koff[a], sP + xb2 + koff[a]);
+        const bf16x8 al = tr_read2(sP + g.lo_off + xa + koff[a], sP + g.lo_off + xb2 + koff[a]);
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) {
+          acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[a][j], 0, 0, 0);
+          acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[a][j], 0, 0, 0);
+          acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[a][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  float* out = slab + (size_t)blockIdx.x * g.nkt * 16 * g.N16;
+#pragma unroll
+  for (int a = 0; a < KTW; ++a) {
+    const int kt = kt0 + a;
+    if (kt < g.nkt) {
+#pragma unroll
+      for (int j = 0; j < NREP; ++j) {
+        const int col = n0 + j * 16 + li;
+        if (col < g.N16) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) out[(size_t)(kt * 16 + lg * 4 + r) * g.N16 + col] = acc[a][j][r];
+        }
+      }
+    }
+  }
+}
+
 // dw[cout][cin][tap] = sum_slices slab[slice][(tap*KT + cin/16)*16 + cin%16][cout]   (fixed order)
 // Block = 64 outputs x 4 slice groups: slice group q sums slices q, q+4, ... with four independent chains.
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slab, int nslices, int nkt, int KT, int N16,
@@ -858,15 +1069,23 @@ int wgrad_patch_launch(const WgradPlan* p, const MdConvDesc* d, const float* src
   const WGeom& g = p->g;
   static const int dbg = getenv("MD_DBG") ? atoi(getenv("MD_DBG")) : 0;
   dim3 grid(p->nslices, g.nkg * g.nng);
+  static const int no_pf = getenv("MD_WGRAD_PF") && atoi(getenv("MD_WGRAD_PF")) == 0;
+  const bool pf = !no_pf && !dbg && g.P * g.C8i <= WPF_X * 256 && PM * g.NC <= WPF_Y * 256 && g.pt < 64 && g.py < 512 &&
+                  g.px < 512 && g.bt < 64;
 #define LAUNCH_WG(KT_, NR_)                                                                                             \
   do {                                                                                                                  \
     static bool set_ = false;                                                                                           \
     if (!set_) {                                                                                                        \
       if (hipFuncSetAttribute((const void*)k_wgrad_patch<KT_, NR_>, hipFuncAttributeMaxDynamicSharedMemorySize,         \
+                              160 * 1024) != hipSuccess ||                                                              \
+          hipFuncSetAttribute((const void*)k_wgrad_patch_pf<KT_, NR_>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
                               160 * 1024) != hipSuccess) return MD_ERR_LAUNCH;                                          \
       set_ = true;                                                                                                      \
     }                                                                                                                   \
-    hipLaunchKernelGGL((k_wgrad_patch<KT_, NR_>), grid, dim3(256), p->lds, s, g, src, ps, psh, slope, dy, slab, dbg);   \
+    if (pf)                                                                                                             \
+      hipLaunchKernelGGL((k_wgrad_patch_pf<KT_, NR_>), grid, dim3(256), p->lds, s, g, src, ps, psh, slope, dy, slab);   \
+    else                                                                                                                \
+      hipLaunchKernelGGL((k_wgrad_patch<KT_, NR_>), grid, dim3(256), p->lds, s, g, src, ps, psh, slope, dy, slab, dbg); \
   } while (0)
 #define LAUNCH_WG_NR(KT_)                                                                                               \
   switch (g.nrep) {                                                                                                     \

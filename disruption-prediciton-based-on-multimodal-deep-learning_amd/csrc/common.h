@@ -38,7 +38,12 @@ struct Geom {
   int N16;      // packed weight rows (destination channels rounded up to 16)
 };
 
-__device__ __forceinline__ float md_leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
+// LeakyReLU: v > 0 ? v : v*slope.  For 0 <= slope <= 1 that is max(v, v*slope) (two VALU ops, no compare/select);
+// bit-identical including v = +-0 and NaN propagation of the multiply.
+__device__ __forceinline__ float md_leaky(float v, float slope) {
+  const float s = v * slope;
+  return (slope >= 0.f && slope <= 1.f) ? fmaxf(v, s) : (v > 0.f ? v : s);
+}
 __device__ __forceinline__ float md_dleaky(float pre, float slope) { return pre > 0.f ? 1.f : slope; }
 
 // ---- unit-stride patch kernel (conv_patch.hip); used by the dispatchers in conv_gemm.hip

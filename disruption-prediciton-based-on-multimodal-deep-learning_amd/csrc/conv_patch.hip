@@ -360,6 +360,253 @@ __global__ __launch_bounds__(256) void k_conv_patch(
 }
 
 // ------------------------------------------------------------------------------------------------
+// Persistent, software-pipelined variant of k_conv_patch (same arithmetic, same results).  A workgroup walks boxes
+// blockIdx.x, blockIdx.x + gridDim.x, ...; the global loads of the NEXT box's patch are issued into registers before
+// the current box's K loop and committed (BN-on-read, hi/lo split, LDS write) after its epilogue, so HBM latency and
+// the per-box set-up overlap the matrix work instead of preceding it.  Everything that does not depend on the box
+// (K-offset table, row offsets, item decode) is computed once per workgroup.  Used when the patch fits
+// PP_ITEMS x 256 items and the strided data-gradient form is not needed.
+// ------------------------------------------------------------------------------------------------
+template <bool F16, int NREP, int PP_ITEMS>
+__global__ __launch_bounds__(256, 2) void k_conv_patch_pp(
+    PGeom g, const float* __restrict__ src, const float* __restrict__ pscale, const float* __restrict__ pshift,
+    float pslope, const uint4* __restrict__ wp, float* __restrict__ dst, float* __restrict__ stat_partial,
+    int accumulate, int n_per_blk, int nboxes) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  char* sP = sm;
+  char* sB = sm + g.off_b;
+  int* sK = (int*)(sm + g.off_koffs);
+  float* sRed = (float*)(sm + g.off_rows);         // [4 waves][2][PNREP*16] epilogue reduction (4.6 KB <= rows+pixg area)
+  float* sScale = (float*)(sm + g.off_scale);
+  float* sShift = sScale + PMAXC;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int n0 = blockIdx.y * n_per_blk;
+  const int ncols = min(n_per_blk, g.N16 - n0);
+  const bool prologue = pscale != nullptr;
+  const int dbg = accumulate >> 8;   // timing experiments: 1 no commit, 2 no K loop, 4 no stores, 8 no loads
+  accumulate &= 1;
+
+  for (int q = t; q < g.nstages * 8; q += 256) {
+    int ko = 0;
+    if (q < g.Kc8) {
+      const int tap = q / g.C8; const int c8 = q - tap * g.C8;
+      const int dt = tap / g.khw; const int r = tap - dt * g.khw;
+      const int dy = r / g.kw; const int dx = r - dy * g.kw;
+      ko = ((dt * g.py + dy) * g.px + dx) * g.ppitch + c8 * 16;
+    }
+    sK[q] = ko;
+  }
+  if (prologue) for (int c = t; c < g.Cps; c += 256) { sScale[c] = pscale[c]; sShift[c] = pshift[c]; }
+
+  // rows of this lane: A-fragment rows (wave*32 + {0,16} + li) and accumulator rows (wave*32 + a*16 + 4*lg + r)
+  auto row_local = [&](int row, int& rt, int& ry, int& rx) {
+    rt = row / g.byx; const int r = row - rt * g.byx; ry = r / g.bx; rx = r - ry * g.bx;
+  };
+  int rp0, rp1;
+  {
+    int rt, ry, rx;
+    row_local(wave * 32 + li, rt, ry, rx);
+    rp0 = rt < g.bt ? ((rt * g.st * g.py + ry * g.sh) * g.px + rx * g.sw) * g.ppitch : 0;
+    row_local(wave * 32 + 16 + li, rt, ry, rx);
+    rp1 = rt < g.bt ? ((rt * g.st * g.py + ry * g.sh) * g.px + rx * g.sw) * g.ppitch : 0;
+  }
+  int orow[2][4];      // packed local coords of the accumulator rows (rt | ry<<6 | rx<<15), -1 outside the box
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int rt, ry, rx;
+      row_local(wave * 32 + a * 16 + lg * 4 + r, rt, ry, rx);
+      orow[a][r] = rt < g.bt ? (rt | (ry << 6) | (rx << 15)) : -1;
+    }
+
+  // box-independent decode of this thread's patch items
+  const int total = g.P * g.C8;
+  const int cv4 = g.Cps >> 2;
+  int iloc[PP_ITEMS], idst[PP_ITEMS];
+#pragma unroll
+  for (int u = 0; u < PP_ITEMS; ++u) {
+    const int item = u * 256 + t;
+    idst[u] = -1; iloc[u] = 0;
+    if (item < total) {
+      const int pixel = g.magicC8 ? (int)__umulhi((unsigned)item, g.magicC8) : item;
+      const int c8 = item - pixel * g.C8;
+      const int ppt = pixel / g.pyx; const int r = pixel - ppt * g.pyx;
+      const int ppy = r / g.px; const int ppx = r - ppy * g.px;
+      iloc[u] = ppt | (ppy << 6) | (ppx << 15) | (c8 << 24);
+      idst[u] = pixel * g.ppitch + c8 * 16;
+    }
+  }
+  float4 va[PP_ITEMS], vb[PP_ITEMS];
+  int fl = 0;
+  auto box_origin = [&](int box, int& n, int& t0, int& y0, int& x0) {
+    int b = box;
+    const int xb = b % g.nbx; b /= g.nbx;
+    const int yb = b % g.nby; b /= g.nby;
+    const int tb = b % g.nbt; n = b / g.nbt;
+    t0 = tb * g.bt; y0 = yb * g.by; x0 = xb * g.bx;
+  };
+  auto issue = [&](int box) {
+    int n, t0, y0, x0;
+    box_origin(box, n, t0, y0, x0);
+    const int ot = t0 * g.st + g.org_t, oh = y0 * g.sh + g.org_h, ow = x0 * g.sw + g.org_w;
+    fl = 0;
+#pragma unroll
+    for (int u = 0; u < PP_ITEMS; ++u) {
+      va[u] = make_float4(0.f, 0.f, 0.f, 0.f); vb[u] = va[u];
+      if (idst[u] >= 0) {
+        const int st = ot + (iloc[u] & 63), sy = oh + ((iloc[u] >> 6) & 511), sx = ow + ((iloc[u] >> 15) & 511);
+        const int c8 = (iloc[u] >> 24) & 255;
+        if (((unsigned)st < (unsigned)g.Ts) && ((unsigned)sy < (unsigned)g.Hs) && ((unsigned)sx < (unsigned)g.Ws) &&
+            c8 * 2 < cv4) {
+          const float* s = src + ((size_t)((n * g.Ts + st) * g.Hs + sy) * g.Ws + sx) * g.Cps + c8 * 8;
+          va[u] = *(const float4*)s;
+          fl |= 1 << (2 * u);
+          if (c8 * 2 + 1 < cv4) vb[u] = *(const float4*)(s + 4); else fl |= 2 << (2 * u);
+        }
+      }
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < PP_ITEMS; ++u) {
+      if (idst[u] >= 0) {
+        float v[8] = {va[u].x, va[u].y, va[u].z, va[u].w, vb[u].x, vb[u].y, vb[u].z, vb[u].w};
+        if (prologue && ((fl >> (2 * u)) & 1)) {
+          const int c8 = (iloc[u] >> 24) & 255;
+          const float* sc = sScale + c8 * 8; const float* sh = sShift + c8 * 8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = md_leaky(fmaf(v[e], sc[e], sh[e]), pslope);
+          if ((fl >> (2 * u)) & 2) { v[4] = v[5] = v[6] = v[7] = 0.f; }
+        }
+        uint4 hi, lo;
+        if (F16) split8_f16(v, hi, lo); else split8(v, hi, lo);
+        *(uint4*)(sP + idst[u]) = hi;
+        *(uint4*)(sP + g.lo_off + idst[u]) = lo;
+      }
+    }
+  };
+
+  const int bchunks = ncols * 8;
+  uint4 rb[2][5];
+  auto load_b = [&](int kb) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint4* base = wp + ((size_t)(kb * 2 + h) * g.N16 + n0) * 8;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int c = t + 256 * i;
+        rb[h][i] = c < bchunks ? base[c] : make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+  const int blo = n_per_blk * PB_PITCH;
+
+  int box = blockIdx.x;
+  if (box < nboxes && !(dbg & 8)) issue(box);
+  for (; box < nboxes; box += gridDim.x) {
+    __syncthreads();                      // previous box: K loop and epilogue reduction done (first: tables in LDS)
+    if (!(dbg & 1)) commit();
+    load_b(0);
+    const int nxt = box + gridDim.x;
+    if (nxt < nboxes && !(dbg & 8)) issue(nxt);         // next box's patch loads stay in flight during the K loop
+
+    f32x4 acc[2][NREP];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int j = 0; j < NREP; ++j) acc[a][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kb = 0; kb < ((dbg & 2) ? 0 : g.nstages); ++kb) {
+      __syncthreads();                    // patch committed (first stage) / previous B tile consumed
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+          const int c = t + 256 * i;
+          if (c < n_per_blk * 8) *(uint4*)(sB + h * blo + (c >> 3) * PB_PITCH + (c & 7) * 16) = rb[h][i];
+        }
+      __syncthreads();
+      if (kb + 1 < g.nstages) load_b(kb + 1);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int ko = sK[kb * 8 + s * 4 + lg];
+        const uint4 ah0 = *(const uint4*)(sP + rp0 + ko), al0 = *(const uint4*)(sP + g.lo_off + rp0 + ko);
+        const uint4 ah1 = *(const uint4*)(sP + rp1 + ko), al1 = *(const uint4*)(sP + g.lo_off + rp1 + ko);
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) {
+          const char* bp = sB + (j * 16 + li) * PB_PITCH + (s * 4 + lg) * 16;
+          const uint4 bh = *(const uint4*)bp, bl = *(const uint4*)(bp + blo);
+          acc[0][j] = mma<F16>(al0, bh, acc[0][j]);
+          acc[1][j] = mma<F16>(al1, bh, acc[1][j]);
+          acc[0][j] = mma<F16>(ah0, bl, acc[0][j]);
+          acc[1][j] = mma<F16>(ah1, bl, acc[1][j]);
+          acc[0][j] = mma<F16>(ah0, bh, acc[0][j]);
+          acc[1][j] = mma<F16>(ah1, bh, acc[1][j]);
+        }
+      }
+    }
+
+    // ---- epilogue
+    int n, t0, y0, x0;
+    box_origin(box, n, t0, y0, x0);
+    int gix[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int oc = orow[a][r];
+        const int ot = t0 + (oc & 63), oy = y0 + ((oc >> 6) & 511), ox = x0 + ((oc >> 15) & 511);
+        gix[a][r] = (oc >= 0 && ot < g.Td && oy < g.Hd && ox < g.Wd) ? ((n * g.Td + ot) * g.Hd + oy) * g.Wd + ox : -1;
+      }
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) {
+      const int col = n0 + j * 16 + li;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int gi = gix[a][r];
+          if (gi >= 0) {
+            float v = acc[a][j][r];
+            s1 += v; s2 = fmaf(v, v, s2);
+            if (col < g.Cpd && !(dbg & 4)) {
+              float* p = dst + (size_t)gi * g.Cpd + col;
+              if (accumulate) v += *p;
+              *p = v;
+            }
+          }
+        }
+      if (stat_partial != nullptr) {
+        s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+        if (lg == 0) {
+          sRed[(wave * 2 + 0) * (PNREP * 16) + j * 16 + li] = s1;
+          sRed[(wave * 2 + 1) * (PNREP * 16) + j * 16 + li] = s2;
+        }
+      }
+    }
+    if (stat_partial != nullptr) {
+      __syncthreads();
+      if (t < ncols && n0 + t < g.Cpd) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          s1 += sRed[(w * 2 + 0) * (PNREP * 16) + t];
+          s2 += sRed[(w * 2 + 1) * (PNREP * 16) + t];
+        }
+        float* sp = stat_partial + (size_t)box * 2 * g.Cpd;
+        sp[n0 + t] = s1;
+        sp[g.Cpd + n0 + t] = s2;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight packing for k_conv_patch: [stage][hi|lo][n (N16)][8 chunks][8 bf16], K order = (tap, 8-channel chunk).
 // mode 0 (forward): n = cout, channel = cin, tap as is.  mode 1 (data gradient): n = cin, channel = cout,
 // tap reversed (the patch walks the flipped filter).
@@ -461,7 +708,7 @@ static bool patch_build(const MdConvDesc* d, int dgrad, PGeom* out, size_t* lds_
   const int nchunks_ = md_cdiv(g.N16, PNREP * 16);
   const int npb_ = md_round_up(md_cdiv(g.N16, nchunks_), 16);
   // LDS: everything but the patch
-  const size_t fixed = (size_t)2 * npb_ * PB_PITCH + (size_t)g.nstages * 8 * 4 + (size_t)PM * 16 + 2 * PMAXC * 4 + 1024;
+  const size_t fixed = (size_t)2 * npb_ * PB_PITCH + (size_t)g.nstages * 8 * 4 + (size_t)PM * 16 + 3072 + 2 * PMAXC * 4 + 1024;
   const size_t cap = 160 * 1024;
   if (fixed + 4096 > cap) return false;
   const long long per_px = (long long)2 * g.ppitch + 4;
@@ -488,7 +735,7 @@ static bool patch_build(const MdConvDesc* d, int dgrad, PGeom* out, size_t* lds_
   if (off < red) off = red;
   g.off_b = (int)off; off += (size_t)2 * npb_ * PB_PITCH;
   g.off_koffs = (int)off; off += (size_t)g.nstages * 8 * 4;
-  g.off_rows = (int)off; off += (size_t)PM * 16;
+  g.off_rows = (int)off; off += (size_t)PM * 16 + 3072;      // >= 4608 B: also the persistent kernel's reduction scratch
   g.off_pixg = (int)off; off += (size_t)((g.P * 4 + 15) & ~15);
   g.off_scale = (int)off; off += (size_t)2 * PMAXC * 4;
   if (off > cap) return false;
@@ -572,7 +819,54 @@ int patch_launch(const PatchPlan* p, const float* src, const float* ps, const fl
     case 8: LAUNCH_PATCH(F16_, STR_, 8); break;                                                                         \
     default: LAUNCH_PATCH(F16_, STR_, 9); break;                                                                        \
   }
-  if (!p->dgrad) { LAUNCH_PATCH_NR(true, false); }
+  // persistent pipelined variant: the patch must fit the register prefetch (3 or 7 items of 32 B per thread; 7 only
+  // with <= 4 column tiles, beyond that the register file spills) and the coordinate packing
+  // Opt-in (MD_PATCH_PP=1): measured neutral on MI355X (c1s 188 -> 181 us, c1t 132 -> 137 us) because a wave's vector
+  // memory operations retire in order: the first B-tile wait of the K loop also waits for the prefetched patch.
+  static const int no_pp = !(getenv("MD_PATCH_PP") && atoi(getenv("MD_PATCH_PP")) == 1);
+  const int nboxes = patch_blocks(p);
+  const int items = md_cdiv(g.P * g.C8, 256);
+  const bool pp = !no_pp && !g.strided && (items <= 3 || (items <= 7 && nrep <= 4)) && g.pt < 64 && g.py < 512 &&
+                  g.px < 512 && g.bt < 64;
+  if (pp) {
+    int wgs = 2 * 256;                            // two workgroups per CU stay resident (LDS-limited)
+    if (wgs > nboxes) wgs = nboxes;
+    dim3 pgrid(wgs, grid.y);
+#define LAUNCH_PP(F16_, NR_, IT_)                                                                                       \
+  do {                                                                                                                  \
+    static bool set_ = false;                                                                                           \
+    if (!set_) {                                                                                                        \
+      if (hipFuncSetAttribute((const void*)k_conv_patch_pp<F16_, NR_, IT_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              160 * 1024) != hipSuccess) return MD_ERR_LAUNCH;                                          \
+      set_ = true;                                                                                                      \
+    }                                                                                                                   \
+    hipLaunchKernelGGL((k_conv_patch_pp<F16_, NR_, IT_>), pgrid, dim3(256), p->lds, s, g, src, ps, psh, slope,          \
+                       (const uint4*)wp, dst, stat, accumulate, npb, nboxes);                                           \
+  } while (0)
+#define LAUNCH_PP_NR(F16_)                                                                                              \
+  if (items <= 3) {                                                                                                     \
+    switch (nrep) {                                                                                                     \
+      case 1: LAUNCH_PP(F16_, 1, 3); break;                                                                             \
+      case 2: LAUNCH_PP(F16_, 2, 3); break;                                                                             \
+      case 3: LAUNCH_PP(F16_, 3, 3); break;                                                                             \
+      case 4: LAUNCH_PP(F16_, 4, 3); break;                                                                             \
+      case 5: LAUNCH_PP(F16_, 5, 3); break;                                                                             \
+      case 6: LAUNCH_PP(F16_, 6, 3); break;                                                                             \
+      case 7: LAUNCH_PP(F16_, 7, 3); break;                                                                             \
+      case 8: LAUNCH_PP(F16_, 8, 3); break;                                                                             \
+      default: LAUNCH_PP(F16_, 9, 3); break;                                                                            \
+    }                                                                                                                   \
+  } else {                                                                                                              \
+    switch (nrep) {                                                                                                     \
+      case 1: LAUNCH_PP(F16_, 1, 7); break;                                                                             \
+      case 2: LAUNCH_PP(F16_, 2, 7); break;                                                                             \
+      case 3: LAUNCH_PP(F16_, 3, 7); break;                                                                             \
+      default: LAUNCH_PP(F16_, 4, 7); break;                                                                            \
+    }                                                                                                                   \
+  }
+    if (!p->dgrad) { LAUNCH_PP_NR(true); } else { LAUNCH_PP_NR(false); }
+  }
+  else if (!p->dgrad) { LAUNCH_PATCH_NR(true, false); }
   else if (!g.strided) { LAUNCH_PATCH_NR(false, false); }
   else { LAUNCH_PATCH_NR(false, true); }
   MD_CHECK_LAUNCH();

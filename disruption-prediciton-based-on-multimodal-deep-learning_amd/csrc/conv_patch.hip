@@ -775,6 +775,64 @@ const PatchPlan* patch_lookup(const MdConvDesc* d, int dgrad) {
   return pp;
 }
 
+// ---- batched weight packing: one launch for every patch-format operand of a network (<= 64 items by value)
+#define PACK_BATCH 64
+struct PackItem { const float* w; unsigned short* out; int Cout, Cin, taps, mode, C8, nstages, N16, f16, total; };
+struct PackBatch { PackItem it[PACK_BATCH]; };
+__global__ __launch_bounds__(256) void k_pack_weights_batch(PackBatch pb) {
+  const PackItem& q = pb.it[blockIdx.y];
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= q.total) return;
+  const int e64 = idx & 63; const int r = idx >> 6;
+  const int n = r % q.N16; const int kb = r / q.N16;
+  const int ch8 = kb * 8 + (e64 >> 3);
+  const int tap = ch8 / q.C8; const int ch = (ch8 - tap * q.C8) * 8 + (e64 & 7);
+  float v = 0.f;
+  if (tap < q.taps) {
+    if (q.mode == 0) { if (n < q.Cout && ch < q.Cin) v = q.w[((size_t)n * q.Cin + ch) * q.taps + tap]; }
+    else if (q.mode == 1) { if (n < q.Cin && ch < q.Cout) v = q.w[((size_t)ch * q.Cin + n) * q.taps + (q.taps - 1 - tap)]; }
+    else { if (n < q.Cin && ch < q.Cout) v = q.w[((size_t)ch * q.Cin + n) * q.taps + tap]; }
+  }
+  const size_t o_hi = ((size_t)(kb * 2 + 0) * q.N16 + n) * 64 + e64;
+  const size_t o_lo = ((size_t)(kb * 2 + 1) * q.N16 + n) * 64 + e64;
+  if (q.f16) {
+    const _Float16 hi = (_Float16)v; const _Float16 lo = (_Float16)(v - (float)hi);
+    q.out[o_hi] = __builtin_bit_cast(unsigned short, hi); q.out[o_lo] = __builtin_bit_cast(unsigned short, lo);
+  } else {
+    const __bf16 hi = (__bf16)v; const __bf16 lo = (__bf16)(v - (float)hi);
+    q.out[o_hi] = __builtin_bit_cast(unsigned short, hi); q.out[o_lo] = __builtin_bit_cast(unsigned short, lo);
+  }
+}
+
+// Packs operand i (descs[i], dgrad[i]) into outs[i] when it uses the patch format and sets handled[i]; others are
+// left to the caller.  One launch per 64 operands.
+int patch_pack_batch(int n, const MdConvDesc* const* descs, const int* dgrad, const float* const* w, float* const* outs,
+                     unsigned char* handled, hipStream_t s) {
+  PackBatch pb; int cnt = 0, maxtot = 0;
+  auto flush = [&]() -> int {
+    if (!cnt) return MD_OK;
+    hipLaunchKernelGGL(k_pack_weights_batch, dim3(md_cdiv(maxtot, 256), cnt), dim3(256), 0, s, pb);
+    MD_CHECK_LAUNCH();
+    cnt = 0; maxtot = 0;
+    return MD_OK;
+  };
+  for (int i = 0; i < n; ++i) {
+    handled[i] = 0;
+    if (!outs[i]) { handled[i] = 1; continue; }
+    const PatchPlan* pp = patch_lookup(descs[i], dgrad[i]);
+    if (!pp) continue;
+    const PGeom& g = pp->g;
+    PackItem& q = pb.it[cnt++];
+    q.w = w[i]; q.out = (unsigned short*)outs[i]; q.Cout = descs[i]->Cout; q.Cin = descs[i]->Cin; q.taps = g.taps;
+    q.mode = dgrad[i] ? (g.strided ? 2 : 1) : 0; q.C8 = g.C8; q.nstages = g.nstages; q.N16 = g.N16; q.f16 = dgrad[i] ? 0 : 1;
+    q.total = g.nstages * g.N16 * 64;
+    if (q.total > maxtot) maxtot = q.total;
+    handled[i] = 1;
+    if (cnt == PACK_BATCH) { int rc = flush(); if (rc) return rc; }
+  }
+  return flush();
+}
+
 size_t patch_wpack_floats(const PatchPlan* p) { return (size_t)p->g.nstages * 2 * p->g.N16 * 64 / 2; }   // bf16 count / 2
 int patch_blocks(const PatchPlan* p) { return p->N * p->g.nbt * p->g.nby * p->g.nbx; }
 

@@ -227,10 +227,28 @@ extern "C" int md_plan_forward(MdPlan* P, const float* x, const float* const* w,
   if (!training && (!rmean || !rvar)) return MD_ERR_NULL;
   float* ws = (float*)workspace;
   RC(md_nchw_to_cl(x, P->B, 3, (int64_t)P->T * P->H * P->W, ws + P->z[0].off, stream));
+  // pack every GEMM operand up front: one batched launch for the patch-format ones, per-unit for the rest
+  {
+    const int n = (int)P->units.size();
+    std::vector<const MdConvDesc*> descs(2 * n); std::vector<int> dg(2 * n);
+    std::vector<const float*> wsrc(2 * n); std::vector<float*> outs(2 * n); std::vector<unsigned char> handled(2 * n);
+    for (int i = 0; i < n; ++i) {
+      const Unit& u = P->units[i];
+      descs[2 * i] = &u.d; dg[2 * i] = 0; wsrc[2 * i] = w[i]; outs[2 * i] = ws + u.wf_off;
+      descs[2 * i + 1] = &u.d; dg[2 * i + 1] = 1; wsrc[2 * i + 1] = w[i];
+      outs[2 * i + 1] = (training && i != 0) ? ws + u.wd_off : nullptr;      // unit 0 (stem) needs no data gradient
+    }
+    RC(patch_pack_batch(2 * n, descs.data(), dg.data(), wsrc.data(), outs.data(), handled.data(), (hipStream_t)stream));
+    for (int i = 0; i < n; ++i) {
+      const Unit& u = P->units[i];
+      float* wf = handled[2 * i] ? nullptr : ws + u.wf_off;
+      float* wd = handled[2 * i + 1] ? nullptr : outs[2 * i + 1];
+      if (wf || wd) RC(md_conv_pack_weights(&u.d, w[i], wf, wd, stream));
+    }
+  }
   size_t next_block = 0;
   for (size_t i = 0; i < P->units.size(); ++i) {
     const Unit& u = P->units[i];
-    RC(md_conv_pack_weights(&u.d, w[i], ws + u.wf_off, training ? ws + u.wd_off : nullptr, stream));
     MdActView in = unit_in_view(P, ws, (int)i);
     float* st = ws + u.stat_off;
     if (training) {

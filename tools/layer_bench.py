@@ -1,4 +1,6 @@
-import sys, os, time; sys.path.insert(0,'.'); sys.path.insert(0,'disruption-prediciton-based-on-multimodal-deep-learning_amd')
+"""Per-layer timing of the conv kernels at the BASELINE shapes (run on the GPU box):  python tools/layer_bench.py [c1s c1t c3s]
+MD_DBG=<bits> ablates phases of the patch kernels (see conv_patch.hip); timings below ~50 us are host-launch bound."""
+import sys, os, time; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'disruption-prediciton-based-on-multimodal-deep-learning_amd'))
 import torch, numpy as np
 from src import ops
 L = {

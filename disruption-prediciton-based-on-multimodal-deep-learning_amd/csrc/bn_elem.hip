@@ -82,36 +82,51 @@ __global__ __launch_bounds__(256) void k_residual_fwd(View skip, View main, floa
   }
 }
 
+// Sum the per-workgroup partial rows [blocks][2][Cp] for channels 4*blockIdx.x .. +3 in fp64: 256 row lanes (row r,
+// r+256, ...) then a fixed tree -- deterministic for a given partial buffer.  Result (8 doubles) in out[] of thread 0.
+__device__ __forceinline__ void reduce_partials4(const float* __restrict__ partial, int blocks, int Cp, double out[8]) {
+  __shared__ double red[8][257];
+  const int r = threadIdx.x;
+  const int c0 = blockIdx.x * 4;
+  double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = r; i < blocks; i += 256) {
+    const float4 s1 = *(const float4*)(partial + (size_t)i * 2 * Cp + c0);
+    const float4 s2 = *(const float4*)(partial + (size_t)i * 2 * Cp + Cp + c0);
+    a[0] += s1.x; a[1] += s1.y; a[2] += s1.z; a[3] += s1.w;
+    a[4] += s2.x; a[5] += s2.y; a[6] += s2.z; a[7] += s2.w;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[k][r] = a[k];
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if (r < st) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) red[k][r] += red[k][r + st];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) out[k] = red[k][0];
+}
+
 // ---------------------------------------------------------------- BatchNorm statistics finalize
-// grid = Cp/4 blocks; thread (c = t&3, r = t>>2) sums partial rows r, r+64, ... in fp64, then a fixed
-// tree over r: deterministic for a given launch geometry.
+// grid = Cp/4 blocks of 256 row lanes (reduce_partials4); threads 0..3 then finish one channel each.
 __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ partial, int blocks, int C, int Cp,
                                                      double inv_count, double unbias, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps, float momentum,
                                                      float* __restrict__ rmean, float* __restrict__ rvar,
                                                      float* __restrict__ mean_o, float* __restrict__ invstd_o,
                                                      float* __restrict__ scale_o, float* __restrict__ shift_o) {
-  __shared__ double s1[64][5], s2[64][5];
-  const int cl = threadIdx.x & 3, r = threadIdx.x >> 2;
-  const int c = blockIdx.x * 4 + cl;
-  double a = 0.0, b = 0.0;
-  if (c < Cp) {
-    for (int i = r; i < blocks; i += 64) {
-      a += (double)partial[(size_t)i * 2 * Cp + c];
-      b += (double)partial[(size_t)i * 2 * Cp + Cp + c];
-    }
-  }
-  s1[r][cl] = a; s2[r][cl] = b;
-  __syncthreads();
-  for (int st = 32; st >= 1; st >>= 1) {
-    if (r < st) { s1[r][cl] += s1[r + st][cl]; s2[r][cl] += s2[r + st][cl]; }
-    __syncthreads();
-  }
+  double tot[8];
+  reduce_partials4(partial, blocks, Cp, tot);
+  const int cl = threadIdx.x, r = threadIdx.x >= 4 ? 1 : 0;      // threads 0..3 finish one channel each
+  const int c = blockIdx.x * 4 + (cl & 3);
+  double s1[1][4] = {{tot[0], tot[1], tot[2], tot[3]}}, s2[1][4] = {{tot[4], tot[5], tot[6], tot[7]}};
   if (r == 0 && c < Cp) {
     float mean = 0.f, invstd = 0.f, sc = 0.f, sh = 0.f;
     if (c < C) {
-      const double m = s1[0][cl] * inv_count;
-      double var = s2[0][cl] * inv_count - m * m;
+      const double m = s1[0][cl & 3] * inv_count;
+      double var = s2[0][cl & 3] * inv_count - m * m;
       if (var < 0.0) var = 0.0;
       const double is = 1.0 / sqrt(var + (double)eps);
       mean = (float)m; invstd = (float)is;
@@ -204,24 +219,13 @@ __global__ __launch_bounds__(256) void k_bn_bwd(const float* __restrict__ dA, Vi
 __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict__ partial, int blocks, int C, int Cp,
                                                          double inv_count, float* __restrict__ dgamma,
                                                          float* __restrict__ dbeta, float* __restrict__ coef) {
-  __shared__ double s1[64][5], s2[64][5];
-  const int cl = threadIdx.x & 3, r = threadIdx.x >> 2;
-  const int c = blockIdx.x * 4 + cl;
-  double a = 0.0, b = 0.0;
-  if (c < Cp) {
-    for (int i = r; i < blocks; i += 64) {
-      a += (double)partial[(size_t)i * 2 * Cp + c];
-      b += (double)partial[(size_t)i * 2 * Cp + Cp + c];
-    }
-  }
-  s1[r][cl] = a; s2[r][cl] = b;
-  __syncthreads();
-  for (int st = 32; st >= 1; st >>= 1) {
-    if (r < st) { s1[r][cl] += s1[r + st][cl]; s2[r][cl] += s2[r + st][cl]; }
-    __syncthreads();
-  }
+  double tot[8];
+  reduce_partials4(partial, blocks, Cp, tot);
+  const int cl = threadIdx.x, r = threadIdx.x >= 4 ? 1 : 0;
+  const int c = blockIdx.x * 4 + (cl & 3);
+  double s1[1][4] = {{tot[0], tot[1], tot[2], tot[3]}}, s2[1][4] = {{tot[4], tot[5], tot[6], tot[7]}};
   if (r == 0 && c < Cp) {
-    const double g1 = s1[0][cl], g2 = s2[0][cl];
+    const double g1 = s1[0][cl & 3], g2 = s2[0][cl & 3];
     if (c < C) { if (dbeta) dbeta[c] = (float)g1; if (dgamma) dgamma[c] = (float)g2; }
     coef[c] = (float)(g1 * inv_count);
     coef[Cp + c] = (float)(g2 * inv_count);

@@ -32,10 +32,25 @@ class _SoftmaxLossFunction(torch.autograd.Function):
         return dl * g, None, None, None, None, None, None
 
 
+_WCACHE = {}
+
+
 def _dev_weight(weight, device):
+    """Class weights on the device.  The reference re-uploads them every call (`self.weight.to(input.device)`,
+    src/loss.py:31); a pageable host-to-device copy synchronises the stream, so the upload is cached per
+    (tensor object, in-place version, device) instead."""
     if weight is None:
         return None
-    return weight.to(device=device, dtype=torch.float32).contiguous()
+    if weight.device == device and weight.dtype == torch.float32 and weight.is_contiguous():
+        return weight
+    key = (id(weight), weight._version, str(device))
+    hit = _WCACHE.get(key)
+    if hit is None or hit[0] is not weight:
+        if len(_WCACHE) > 64:
+            _WCACHE.clear()
+        hit = (weight, weight.to(device=device, dtype=torch.float32).contiguous())
+        _WCACHE[key] = hit
+    return hit[1]
 
 
 class FocalLoss(nn.Module):

@@ -289,7 +289,7 @@ extern "C" int md_bn_finalize(const float* stat_partial, int32_t blocks, int32_t
   if (C <= 0 || blocks <= 0 || count <= 0) return MD_ERR_BAD_SHAPE;
   const int Cp = md_cpad(C);
   const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
-  hipLaunchKernelGGL(k_bn_finalize, dim3(md_cdiv(Cp, 4)), dim3(256), 0, (hipStream_t)stream, stat_partial, blocks, C, Cp,
+  MD_KLAUNCH(k_bn_finalize, dim3(md_cdiv(Cp, 4)), dim3(256), 0, (hipStream_t)stream, stat_partial, blocks, C, Cp,
                      1.0 / (double)count, unbias, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
                      scale, shift);
   MD_CHECK_LAUNCH();
@@ -301,7 +301,7 @@ extern "C" int md_bn_eval_params(int32_t C, const float* gamma, const float* bet
   if (!gamma || !beta || !rmean || !rvar || !mean || !invstd || !scale || !shift) return MD_ERR_NULL;
   if (C <= 0) return MD_ERR_BAD_SHAPE;
   const int Cp = md_cpad(C);
-  hipLaunchKernelGGL(k_bn_eval_params, dim3(md_cdiv(Cp, 256)), dim3(256), 0, (hipStream_t)stream, C, Cp, gamma, beta, rmean,
+  MD_KLAUNCH(k_bn_eval_params, dim3(md_cdiv(Cp, 256)), dim3(256), 0, (hipStream_t)stream, C, Cp, gamma, beta, rmean,
                      rvar, eps, mean, invstd, scale, shift);
   MD_CHECK_LAUNCH();
   return MD_OK;
@@ -317,7 +317,7 @@ extern "C" int md_bn_act(const MdActView* x, int64_t rows, int32_t C, float* out
   if (!x || !x->data || !out) return MD_ERR_NULL;
   int rc = check_rows(rows, C); if (rc) return rc;
   const int C4 = md_cpad(C) / 4;
-  hipLaunchKernelGGL(k_bn_act, dim3(stream_blocks(rows, C4)), dim3(256), 0, (hipStream_t)stream, to_view(x), rows, C4, out);
+  MD_KLAUNCH(k_bn_act, dim3(stream_blocks(rows, C4)), dim3(256), 0, (hipStream_t)stream, to_view(x), rows, C4, out);
   MD_CHECK_LAUNCH();
   return MD_OK;
 }
@@ -327,7 +327,7 @@ extern "C" int md_residual_fwd(const MdActView* skip, const MdActView* main, flo
   if (!skip || !main || !skip->data || !main->data || !z) return MD_ERR_NULL;
   int rc = check_rows(rows, C); if (rc) return rc;
   const int C4 = md_cpad(C) / 4;
-  hipLaunchKernelGGL(k_residual_fwd, dim3(stream_blocks(rows, C4)), dim3(256), 0, (hipStream_t)stream, to_view(skip),
+  MD_KLAUNCH(k_residual_fwd, dim3(stream_blocks(rows, C4)), dim3(256), 0, (hipStream_t)stream, to_view(skip),
                      to_view(main), alpha, rows, C4, z);
   MD_CHECK_LAUNCH();
   return MD_OK;
@@ -349,7 +349,7 @@ extern "C" int md_bn_bwd_reduce(const float* dA, const MdActView* main, const Md
   if (!dA || !main || !main->data || !mean || !invstd || !partial) return MD_ERR_NULL;
   int rc = check_rows(rows, C); if (rc) return rc;
   const int C4 = md_cpad(C) / 4;
-  hipLaunchKernelGGL(k_bn_bwd<false>, dim3(md_bn_bwd_blocks(rows, C)), dim3(256), 0, (hipStream_t)stream, dA,
+  MD_KLAUNCH(k_bn_bwd<false>, dim3(md_bn_bwd_blocks(rows, C)), dim3(256), 0, (hipStream_t)stream, dA,
                      to_view(main), to_view(skip), skip != nullptr ? 1 : 0, alpha, mean, invstd, (const float*)nullptr,
                      rows, C4, partial, (float*)nullptr, (float*)nullptr);
   MD_CHECK_LAUNCH();
@@ -361,7 +361,7 @@ extern "C" int md_bn_bwd_finalize(const float* partial, int32_t blocks, int32_t 
   if (!partial || !coef) return MD_ERR_NULL;
   if (C <= 0 || blocks <= 0 || count <= 0) return MD_ERR_BAD_SHAPE;
   const int Cp = md_cpad(C);
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(md_cdiv(Cp, 4)), dim3(256), 0, (hipStream_t)stream, partial, blocks, C, Cp,
+  MD_KLAUNCH(k_bn_bwd_finalize, dim3(md_cdiv(Cp, 4)), dim3(256), 0, (hipStream_t)stream, partial, blocks, C, Cp,
                      1.0 / (double)count, dgamma, dbeta, coef);
   MD_CHECK_LAUNCH();
   return MD_OK;
@@ -374,7 +374,7 @@ extern "C" int md_bn_bwd_apply(const float* dA, const MdActView* main, const MdA
   if (skip != nullptr && !dS) return MD_ERR_NULL;
   int rc = check_rows(rows, C); if (rc) return rc;
   const int C4 = md_cpad(C) / 4;
-  hipLaunchKernelGGL(k_bn_bwd<true>, dim3(stream_blocks(rows, C4)), dim3(256), 0, (hipStream_t)stream, dA, to_view(main),
+  MD_KLAUNCH(k_bn_bwd<true>, dim3(stream_blocks(rows, C4)), dim3(256), 0, (hipStream_t)stream, dA, to_view(main),
                      to_view(skip), skip != nullptr ? 1 : 0, alpha, mean, invstd, coef, rows, C4, (float*)nullptr,
                      d_raw, dS);
   MD_CHECK_LAUNCH();
@@ -386,7 +386,7 @@ extern "C" int md_nchw_to_cl(const float* x, int32_t B, int32_t C, int64_t thw, 
   if (B <= 0 || C <= 0 || thw <= 0) return MD_ERR_BAD_SHAPE;
   const int C4 = md_cpad(C) / 4;
   const int64_t total = (int64_t)B * thw * C4;
-  hipLaunchKernelGGL(k_nchw_to_cl, dim3((unsigned)md_cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, x, C, C4, thw,
+  MD_KLAUNCH(k_nchw_to_cl, dim3((unsigned)md_cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, x, C, C4, thw,
                      total, out);
   MD_CHECK_LAUNCH();
   return MD_OK;
@@ -395,7 +395,7 @@ extern "C" int md_cl_to_nchw(const float* x, int32_t B, int32_t C, int64_t thw, 
   if (!x || !out) return MD_ERR_NULL;
   if (B <= 0 || C <= 0 || thw <= 0) return MD_ERR_BAD_SHAPE;
   const int64_t total = (int64_t)B * C * thw;
-  hipLaunchKernelGGL(k_cl_to_nchw, dim3((unsigned)md_cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, x, C, md_cpad(C),
+  MD_KLAUNCH(k_cl_to_nchw, dim3((unsigned)md_cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, x, C, md_cpad(C),
                      thw, total, out);
   MD_CHECK_LAUNCH();
   return MD_OK;
@@ -405,7 +405,7 @@ extern "C" int md_avgpool_fwd(const float* x, int32_t B, int32_t C, int64_t thw,
   if (!x || !feat) return MD_ERR_NULL;
   int rc = check_rows(thw, C); if (rc) return rc;
   if (B <= 0) return MD_ERR_BAD_SHAPE;
-  hipLaunchKernelGGL(k_avgpool_fwd, dim3(B), dim3(256), 0, (hipStream_t)stream, x, C, md_cpad(C) / 4, thw, feat);
+  MD_KLAUNCH(k_avgpool_fwd, dim3(B), dim3(256), 0, (hipStream_t)stream, x, C, md_cpad(C) / 4, thw, feat);
   MD_CHECK_LAUNCH();
   return MD_OK;
 }
@@ -414,7 +414,7 @@ extern "C" int md_avgpool_bwd(const float* dfeat, int32_t B, int32_t C, int64_t 
   if (B <= 0 || C <= 0 || thw <= 0) return MD_ERR_BAD_SHAPE;
   const int C4 = md_cpad(C) / 4;
   const int64_t total = (int64_t)B * thw * C4;
-  hipLaunchKernelGGL(k_avgpool_bwd, dim3((unsigned)md_cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, dfeat, C, C4, thw,
+  MD_KLAUNCH(k_avgpool_bwd, dim3((unsigned)md_cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, dfeat, C, C4, thw,
                      total, dx);
   MD_CHECK_LAUNCH();
   return MD_OK;

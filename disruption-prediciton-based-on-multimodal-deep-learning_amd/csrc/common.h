@@ -12,6 +12,14 @@ static inline int md_cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t md_cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int md_round_up(int a, int b) { return md_cdiv(a, b) * b; }
 
+// hipGetLastError() reports the last error of ANY earlier HIP call on this thread (e.g. a benign failure inside the
+// host framework's start-up), so the sticky state is cleared right before every launch and read right after it.
+#define MD_KLAUNCH(...)              \
+  do {                               \
+    (void)hipGetLastError();         \
+    hipLaunchKernelGGL(__VA_ARGS__); \
+  } while (0)
+
 #define MD_CHECK_LAUNCH()                                  \
   do {                                                     \
     hipError_t e__ = hipGetLastError();                    \

@@ -446,7 +446,7 @@ extern "C" int md_conv_pack_weights(const MdConvDesc* d, const float* w, float* 
   const int nF = wf ? gf.N16 * gf.Kp : 0, nD = wd ? gd.N16 * gd.Kp : 0;
   const int n = nF > nD ? nF : nD;
   if (n == 0) return MD_OK;
-  hipLaunchKernelGGL(k_pack_weights, dim3(md_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w, d->Cout, d->Cin,
+  MD_KLAUNCH(k_pack_weights, dim3(md_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w, d->Cout, d->Cin,
                      taps, wf, gf.Cpi, gf.Kp, gf.N16, wd, gd.Cpi, gd.Kp, gd.N16);
   MD_CHECK_LAUNCH();
   return MD_OK;
@@ -469,7 +469,7 @@ static int launch_gemm(const Geom& g, const float* src, const float* ps, const f
     hipFuncSetAttribute((const void*)k_conv_gemm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_conv_gemm, grid, dim3(256), lds, s, g, src, ps, psh, slope, wp, dst, stat, accumulate, npb);
+  MD_KLAUNCH(k_conv_gemm, grid, dim3(256), lds, s, g, src, ps, psh, slope, wp, dst, stat, accumulate, npb);
   MD_CHECK_LAUNCH();
   return MD_OK;
 }
@@ -526,7 +526,7 @@ extern "C" int md_conv_wgrad(const MdConvDesc* d, const MdActView* x, const floa
   if (slices > 65535) return MD_ERR_UNSUPPORTED;
   dim3 grid(ktiles, slices, nchunks);
   const size_t lds = (size_t)(WR * PX + WR * PY) * 4;
-  hipLaunchKernelGGL(k_conv_wgrad, grid, dim3(256), lds, (hipStream_t)stream, g, x->data, x->scale, x->shift,
+  MD_KLAUNCH(k_conv_wgrad, grid, dim3(256), lds, (hipStream_t)stream, g, x->data, x->scale, x->shift,
                      x->slope, dy_raw, dw, d->Cin, d->Cout, taps, rows_per_blk, npb);
   MD_CHECK_LAUNCH();
   return MD_OK;

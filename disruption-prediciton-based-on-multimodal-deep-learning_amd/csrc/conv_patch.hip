@@ -811,7 +811,7 @@ int patch_pack_batch(int n, const MdConvDesc* const* descs, const int* dgrad, co
   PackBatch pb; int cnt = 0, maxtot = 0;
   auto flush = [&]() -> int {
     if (!cnt) return MD_OK;
-    hipLaunchKernelGGL(k_pack_weights_batch, dim3(md_cdiv(maxtot, 256), cnt), dim3(256), 0, s, pb);
+    MD_KLAUNCH(k_pack_weights_batch, dim3(md_cdiv(maxtot, 256), cnt), dim3(256), 0, s, pb);
     MD_CHECK_LAUNCH();
     cnt = 0; maxtot = 0;
     return MD_OK;
@@ -839,7 +839,7 @@ int patch_blocks(const PatchPlan* p) { return p->N * p->g.nbt * p->g.nby * p->g.
 int patch_pack(const MdConvDesc* d, int dgrad, const PatchPlan* p, const float* w, float* out, hipStream_t s) {
   const PGeom& g = p->g;
   const int total = g.nstages * g.N16 * 64;
-  hipLaunchKernelGGL(k_pack_weights_x3, dim3(md_cdiv(total, 256)), dim3(256), 0, s, w, d->Cout, d->Cin, g.taps, dgrad ? (g.strided ? 2 : 1) : 0, g.C8,
+  MD_KLAUNCH(k_pack_weights_x3, dim3(md_cdiv(total, 256)), dim3(256), 0, s, w, d->Cout, d->Cin, g.taps, dgrad ? (g.strided ? 2 : 1) : 0, g.C8,
                      g.nstages, g.N16, (unsigned short*)out, dgrad ? 0 : 1);
   MD_CHECK_LAUNCH();
   return MD_OK;
@@ -862,7 +862,7 @@ int patch_launch(const PatchPlan* p, const float* src, const float* ps, const fl
                               160 * 1024) != hipSuccess) return MD_ERR_LAUNCH;                                          \
       set_ = true;                                                                                                      \
     }                                                                                                                   \
-    hipLaunchKernelGGL((k_conv_patch<F16_, STR_, NR_>), grid, dim3(256), p->lds, s, g, src, ps, psh, slope,             \
+    MD_KLAUNCH((k_conv_patch<F16_, STR_, NR_>), grid, dim3(256), p->lds, s, g, src, ps, psh, slope,             \
                        (const uint4*)wp, dst, stat, accumulate, npb);                                                   \
   } while (0)
 #define LAUNCH_PATCH_NR(F16_, STR_)                                                                                     \
@@ -898,7 +898,7 @@ int patch_launch(const PatchPlan* p, const float* src, const float* ps, const fl
                               160 * 1024) != hipSuccess) return MD_ERR_LAUNCH;                                          \
       set_ = true;                                                                                                      \
     }                                                                                                                   \
-    hipLaunchKernelGGL((k_conv_patch_pp<F16_, NR_, IT_>), pgrid, dim3(256), p->lds, s, g, src, ps, psh, slope,          \
+    MD_KLAUNCH((k_conv_patch_pp<F16_, NR_, IT_>), pgrid, dim3(256), p->lds, s, g, src, ps, psh, slope,          \
                        (const uint4*)wp, dst, stat, accumulate, npb, nboxes);                                           \
   } while (0)
 #define LAUNCH_PP_NR(F16_)                                                                                              \
@@ -1435,9 +1435,9 @@ int wgrad_patch_launch(const WgradPlan* p, const MdConvDesc* d, const float* src
       set_ = true;                                                                                                      \
     }                                                                                                                   \
     if (pf)                                                                                                             \
-      hipLaunchKernelGGL((k_wgrad_patch_pf<KT_, NR_>), grid, dim3(256), p->lds, s, g, src, ps, psh, slope, dy, slab);   \
+      MD_KLAUNCH((k_wgrad_patch_pf<KT_, NR_>), grid, dim3(256), p->lds, s, g, src, ps, psh, slope, dy, slab);   \
     else                                                                                                                \
-      hipLaunchKernelGGL((k_wgrad_patch<KT_, NR_>), grid, dim3(256), p->lds, s, g, src, ps, psh, slope, dy, slab, dbg); \
+      MD_KLAUNCH((k_wgrad_patch<KT_, NR_>), grid, dim3(256), p->lds, s, g, src, ps, psh, slope, dy, slab, dbg); \
   } while (0)
 #define LAUNCH_WG_NR(KT_)                                                                                               \
   switch (g.nrep) {                                                                                                     \
@@ -1450,7 +1450,7 @@ int wgrad_patch_launch(const WgradPlan* p, const MdConvDesc* d, const float* src
   if (g.ktw == 3) { LAUNCH_WG_NR(3); } else { LAUNCH_WG_NR(5); }
   MD_CHECK_LAUNCH();
   const int total = g.nkt * 16 * g.N16;
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3(md_cdiv(total, 64)), dim3(256), 0, s, slab, p->nslices, g.nkt, g.KT, g.N16, d->Cout,
+  MD_KLAUNCH(k_wgrad_reduce, dim3(md_cdiv(total, 64)), dim3(256), 0, s, slab, p->nslices, g.nkt, g.KT, g.N16, d->Cout,
                      d->Cin, g.taps, dw);
   MD_CHECK_LAUNCH();
   return MD_OK;

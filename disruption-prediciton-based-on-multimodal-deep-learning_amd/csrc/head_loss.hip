@@ -113,7 +113,7 @@ extern "C" int md_head_fwd(const float* feat, int32_t B, int32_t D, int32_t Hd, 
   if (B <= 0 || D <= 0 || Hd <= 0 || K <= 0) return MD_ERR_BAD_SHAPE;
   const size_t lds = (size_t)2 * B * Hd * 4;
   if (lds > 60000) return MD_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(k_head_fwd, dim3(1), dim3(256), lds, (hipStream_t)stream, feat, B, D, Hd, K, w0, b0, gamma, beta, w1,
+  MD_KLAUNCH(k_head_fwd, dim3(1), dim3(256), lds, (hipStream_t)stream, feat, B, D, Hd, K, w0, b0, gamma, beta, w1,
                      b1, alpha, eps, momentum, training, running_mean, running_var, logits, save);
   MD_CHECK_LAUNCH();
   return MD_OK;
@@ -128,7 +128,7 @@ extern "C" int md_head_bwd(const float* dlogits, const float* feat, int32_t B, i
   if (B <= 0 || D <= 0 || Hd <= 0 || K <= 0) return MD_ERR_BAD_SHAPE;
   const size_t lds = (size_t)B * Hd * 4;
   if (lds > 60000) return MD_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(k_head_bwd, dim3(1), dim3(256), lds, (hipStream_t)stream, dlogits, feat, B, D, Hd, K, w0, gamma, w1,
+  MD_KLAUNCH(k_head_bwd, dim3(1), dim3(256), lds, (hipStream_t)stream, dlogits, feat, B, D, Hd, K, w0, gamma, w1,
                      alpha, save, dfeat, dw0, db0, dgamma, dbeta, dw1, db1);
   MD_CHECK_LAUNCH();
   return MD_OK;
@@ -205,7 +205,7 @@ extern "C" int md_softmax_loss(int32_t kind, const float* logits, const int64_t*
   if (kind < 0 || kind > 2) return MD_ERR_UNSUPPORTED;
   if (B <= 0 || K <= 0) return MD_ERR_BAD_SHAPE;
   if (K > MAXK) return MD_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(k_softmax_loss, dim3(1), dim3(256), 0, (hipStream_t)stream, kind, logits, target, B, K, class_weight,
+  MD_KLAUNCH(k_softmax_loss, dim3(1), dim3(256), 0, (hipStream_t)stream, kind, logits, target, B, K, class_weight,
                      margins, gamma_or_s, loss, dlogits, pred);
   MD_CHECK_LAUNCH();
   return MD_OK;

@@ -9,6 +9,11 @@ import ctypes as C
 import os
 import threading
 
+# PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so).  It must be in the process BEFORE this library is
+# dlopen'ed so that both resolve to the same runtime; loaded the other way round the process holds two HIP runtimes
+# and every launch on a torch stream fails (measured: "kernel launch failed" from md_plan_forward).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libmi355x_disrupt.so")
 

@@ -16,6 +16,7 @@
 // LDS pixel pitch is 16*(4m+2) bytes so that the 16 lanes of each ds_read_b128 group cover 16 distinct 16-byte
 // slots (conflict-free for rows that are consecutive pixels).
 #include "common.h"
+#include <cstdlib>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -647,7 +648,8 @@ __global__ void k_pack_weights_x3(const float* __restrict__ w, int Cout, int Cin
 static int pitch_for(int C8) {          // smallest 16*(4m+2) >= 16*C8
   int u = C8;
   while ((u & 3) != 2) ++u;
-  return u * 16;
+  static const int add = getenv("MD_PITCH_ADD") ? atoi(getenv("MD_PITCH_ADD")) : 0;   // experiments only
+  return (u + add) * 16;
 }
 
 // Choose the output box (bt,by,bx), <= 128 pixels, minimising (boxes) x (MFMA rows + weighted patch pixels).
@@ -713,7 +715,8 @@ static bool patch_build(const MdConvDesc* d, int dgrad, PGeom* out, size_t* lds_
   if (fixed + 4096 > cap) return false;
   const long long per_px = (long long)2 * g.ppitch + 4;
   long long maxP = (long long)(cap - fixed) / per_px - 2;
-  long long softP = (long long)(cap / 2 - fixed) / per_px - 2;
+  static const int soft_kb = getenv("MD_LDS_SOFT_KB") ? atoi(getenv("MD_LDS_SOFT_KB")) : 80;   // target LDS per workgroup
+  long long softP = ((long long)soft_kb * 1024 - (long long)fixed) / per_px - 2;
   const long long idx_cap = 65535 / g.C8;              // item index must stay below 2^16 for the magic division
   if (maxP > idx_cap) maxP = idx_cap;
   if (softP < 1) softP = 1;

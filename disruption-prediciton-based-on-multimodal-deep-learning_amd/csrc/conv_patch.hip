@@ -49,6 +49,7 @@ struct PGeom {
   int N16;
   unsigned magicC8;         // floor(2^32 / C8) + 1 : exact item / C8 for item < 2^16
   int off_b, off_koffs, off_rows, off_pixg, off_scale;   // LDS byte offsets
+  int pack2, pk_shift, pk_kw; // pixel-pair reinterpretation of a <=4-channel, W-stride-2 input (see patch_build)
 };
 
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(256) void k_conv_patch(
     }
     sK[q] = ko;
   }
-  if (prologue) for (int c = t; c < g.Cps; c += 256) { sScale[c] = pscale[c]; sShift[c] = pshift[c]; }
+  if (prologue) for (int c = t; c < g.Cps; c += 256) { const int cs = g.pack2 ? (c & 3) : c; sScale[c] = pscale[cs]; sShift[c] = pshift[cs]; }
 
   // ---- B tile prefetch (registers): [stage][hi|lo][N16][8 chunks] uint4, this block's rows n0..n0+ncols
   const int bchunks = ncols * 8;                 // per half
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_patch_pp(
     }
     sK[q] = ko;
   }
-  if (prologue) for (int c = t; c < g.Cps; c += 256) { sScale[c] = pscale[c]; sShift[c] = pshift[c]; }
+  if (prologue) for (int c = t; c < g.Cps; c += 256) { const int cs = g.pack2 ? (c & 3) : c; sScale[c] = pscale[cs]; sShift[c] = pshift[cs]; }
 
   // rows of this lane: A-fragment rows (wave*32 + {0,16} + li) and accumulator rows (wave*32 + a*16 + 4*lg + r)
   auto row_local = [&](int row, int& rt, int& ry, int& rx) {
@@ -612,8 +613,20 @@ __global__ __launch_bounds__(256, 2) void k_conv_patch_pp(
 // mode 0 (forward): n = cout, channel = cin, tap as is.  mode 1 (data gradient): n = cin, channel = cout,
 // tap reversed (the patch walks the flipped filter).
 // ------------------------------------------------------------------------------------------------
+// mode 3 (pixel-pair reinterpretation, forward): the packed filter has kwp super-taps of 8 channels = 2 pixels x 4;
+// super-tap sx', channel 4j+c  <->  real tap dx = 2 sx' + j + shift, channel c.
+__device__ __forceinline__ float pack2_weight(const float* __restrict__ w, int n, int tap, int ch, int Cout, int Cin, int kwp,
+                                              int kw_real, int shift, int taps_real) {
+  const int sx = tap % kwp, row = tap / kwp;            // row = dt*kh + dy
+  const int j = ch >> 2, c = ch & 3;
+  const int dx = 2 * sx + j + shift;
+  if (n < Cout && c < Cin && dx >= 0 && dx < kw_real) return w[((size_t)n * Cin + c) * taps_real + row * kw_real + dx];
+  return 0.f;
+}
+
 __global__ void k_pack_weights_x3(const float* __restrict__ w, int Cout, int Cin, int taps, int mode, int C8, int nstages,
-                                  int N16, unsigned short* __restrict__ out, int f16) {
+                                  int N16, unsigned short* __restrict__ out, int f16, int kwp = 0, int kw_real = 0,
+                                  int shift = 0, int taps_real = 0) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;     // over [stage][n][64]
   const int total = nstages * N16 * 64;
   if (idx >= total) return;
@@ -625,7 +638,8 @@ __global__ void k_pack_weights_x3(const float* __restrict__ w, int Cout, int Cin
   if (tap < taps) {
     if (mode == 0) { if (n < Cout && ch < Cin) v = w[((size_t)n * Cin + ch) * taps + tap]; }
     else if (mode == 1) { if (n < Cin && ch < Cout) v = w[((size_t)ch * Cin + n) * taps + (taps - 1 - tap)]; }
-    else { if (n < Cin && ch < Cout) v = w[((size_t)ch * Cin + n) * taps + tap]; }
+    else if (mode == 2) { if (n < Cin && ch < Cout) v = w[((size_t)ch * Cin + n) * taps + tap]; }
+    else v = pack2_weight(w, n, tap, ch, Cout, Cin, kwp, kw_real, shift, taps_real);
   }
   const size_t o_hi = ((size_t)(kb * 2 + 0) * N16 + n) * 64 + e64;
   const size_t o_lo = ((size_t)(kb * 2 + 1) * N16 + n) * 64 + e64;
@@ -700,6 +714,22 @@ static bool patch_build(const MdConvDesc* d, int dgrad, PGeom* out, size_t* lds_
   g.kh = d->kh; g.kw = d->kw; g.khw = d->kh * d->kw; g.taps = d->kt * g.khw;
   if (!dgrad) { g.org_t = -d->pt; g.org_h = -d->ph; g.org_w = -d->pw; }
   else { g.org_t = d->pt - (d->kt - 1); g.org_h = d->ph - (d->kh - 1); g.org_w = d->pw - (d->kw - 1); }
+  // Pixel-pair reinterpretation (forward): a <= 4-channel input read with W-stride 2 (the stem) would fill only half
+  // of every 8-channel K chunk.  The same memory is a [.., Wi/2][8] tensor of pixel pairs, over which the convolution
+  // has unit W-stride and kwp = ceil-ish(kw/2)+1 super-taps: output x reads pairs x + lo .. x + hi, and super-tap sx',
+  // channel 4j+c carries real tap dx = 2 sx' + j + shift (zero weight where dx falls outside the filter).
+  g.pack2 = 0; g.pk_shift = 0; g.pk_kw = d->kw;
+  static const int no_pack2 = getenv("MD_PACK2") && atoi(getenv("MD_PACK2")) == 0;
+  int kw_eff = d->kw, sw_eff = g.sw;
+  if (!dgrad && !no_pack2 && g.Cps == 4 && d->sw == 2 && (d->Wi & 1) == 0 && d->kw >= 2) {
+    const int lo = -((d->pw + 1) / 2);
+    const int num = d->kw - 1 - d->pw;
+    const int hi = num >= 0 ? num / 2 : -((-num + 1) / 2);
+    g.pack2 = 1; g.pk_shift = d->pw + 2 * lo; g.pk_kw = d->kw;
+    g.kw = hi - lo + 1; g.khw = g.kh * g.kw; g.taps = d->kt * g.khw;
+    g.org_w = lo; g.sw = 1; g.Ws = d->Wi / 2; g.Cps = 8;
+    kw_eff = g.kw; sw_eff = 1;
+  }
   g.C8 = (g.Cps + 7) / 8;
   g.ppitch = pitch_for(g.C8);
   g.Kc8 = g.taps * g.C8;
@@ -721,12 +751,12 @@ static bool patch_build(const MdConvDesc* d, int dgrad, PGeom* out, size_t* lds_
   if (maxP > idx_cap) maxP = idx_cap;
   if (softP < 1) softP = 1;
   if (maxP < 1) return false;
-  if (!choose_box(g.Td, g.Hd, g.Wd, d->kt, d->kh, d->kw, sdg ? d->st : g.st, sdg ? d->sh : g.sh, sdg ? d->sw : g.sw, sdg,
+  if (!choose_box(g.Td, g.Hd, g.Wd, d->kt, d->kh, kw_eff, sdg ? d->st : g.st, sdg ? d->sh : g.sh, sdg ? d->sw : sw_eff, sdg,
                   (int)maxP, (int)softP, &g.bt, &g.by, &g.bx)) return false;
   g.byx = g.by * g.bx;
   g.nbt = md_cdiv(g.Td, g.bt); g.nby = md_cdiv(g.Hd, g.by); g.nbx = md_cdiv(g.Wd, g.bx);
   if (!sdg) {
-    g.pt = (g.bt - 1) * g.st + d->kt; g.py = (g.by - 1) * g.sh + d->kh; g.px = (g.bx - 1) * g.sw + d->kw;
+    g.pt = (g.bt - 1) * g.st + d->kt; g.py = (g.by - 1) * g.sh + d->kh; g.px = (g.bx - 1) * g.sw + g.kw;
   } else {
     g.pt = (g.bt + d->kt - 2) / d->st + 2; g.py = (g.by + d->kh - 2) / d->sh + 2; g.px = (g.bx + d->kw - 2) / d->sw + 2;
   }
@@ -780,7 +810,7 @@ const PatchPlan* patch_lookup(const MdConvDesc* d, int dgrad) {
 
 // ---- batched weight packing: one launch for every patch-format operand of a network (<= 64 items by value)
 #define PACK_BATCH 64
-struct PackItem { const float* w; unsigned short* out; int Cout, Cin, taps, mode, C8, nstages, N16, f16, total; };
+struct PackItem { const float* w; unsigned short* out; int Cout, Cin, taps, mode, C8, nstages, N16, f16, total, kwp, kw_real, shift, taps_real; };
 struct PackBatch { PackItem it[PACK_BATCH]; };
 __global__ __launch_bounds__(256) void k_pack_weights_batch(PackBatch pb) {
   const PackItem& q = pb.it[blockIdx.y];
@@ -794,7 +824,8 @@ __global__ __launch_bounds__(256) void k_pack_weights_batch(PackBatch pb) {
   if (tap < q.taps) {
     if (q.mode == 0) { if (n < q.Cout && ch < q.Cin) v = q.w[((size_t)n * q.Cin + ch) * q.taps + tap]; }
     else if (q.mode == 1) { if (n < q.Cin && ch < q.Cout) v = q.w[((size_t)ch * q.Cin + n) * q.taps + (q.taps - 1 - tap)]; }
-    else { if (n < q.Cin && ch < q.Cout) v = q.w[((size_t)ch * q.Cin + n) * q.taps + tap]; }
+    else if (q.mode == 2) { if (n < q.Cin && ch < q.Cout) v = q.w[((size_t)ch * q.Cin + n) * q.taps + tap]; }
+    else v = pack2_weight(q.w, n, tap, ch, q.Cout, q.Cin, q.kwp, q.kw_real, q.shift, q.taps_real);
   }
   const size_t o_hi = ((size_t)(kb * 2 + 0) * q.N16 + n) * 64 + e64;
   const size_t o_lo = ((size_t)(kb * 2 + 1) * q.N16 + n) * 64 + e64;
@@ -827,7 +858,9 @@ int patch_pack_batch(int n, const MdConvDesc* const* descs, const int* dgrad, co
     const PGeom& g = pp->g;
     PackItem& q = pb.it[cnt++];
     q.w = w[i]; q.out = (unsigned short*)outs[i]; q.Cout = descs[i]->Cout; q.Cin = descs[i]->Cin; q.taps = g.taps;
-    q.mode = dgrad[i] ? (g.strided ? 2 : 1) : 0; q.C8 = g.C8; q.nstages = g.nstages; q.N16 = g.N16; q.f16 = dgrad[i] ? 0 : 1;
+    q.mode = dgrad[i] ? (g.strided ? 2 : 1) : (g.pack2 ? 3 : 0); q.C8 = g.C8; q.nstages = g.nstages; q.N16 = g.N16;
+    q.f16 = dgrad[i] ? 0 : 1;
+    q.kwp = g.kw; q.kw_real = g.pk_kw; q.shift = g.pk_shift; q.taps_real = descs[i]->kt * descs[i]->kh * descs[i]->kw;
     q.total = g.nstages * g.N16 * 64;
     if (q.total > maxtot) maxtot = q.total;
     handled[i] = 1;
@@ -842,8 +875,9 @@ int patch_blocks(const PatchPlan* p) { return p->N * p->g.nbt * p->g.nby * p->g.
 int patch_pack(const MdConvDesc* d, int dgrad, const PatchPlan* p, const float* w, float* out, hipStream_t s) {
   const PGeom& g = p->g;
   const int total = g.nstages * g.N16 * 64;
-  MD_KLAUNCH(k_pack_weights_x3, dim3(md_cdiv(total, 256)), dim3(256), 0, s, w, d->Cout, d->Cin, g.taps, dgrad ? (g.strided ? 2 : 1) : 0, g.C8,
-                     g.nstages, g.N16, (unsigned short*)out, dgrad ? 0 : 1);
+  MD_KLAUNCH(k_pack_weights_x3, dim3(md_cdiv(total, 256)), dim3(256), 0, s, w, d->Cout, d->Cin, g.taps,
+             dgrad ? (g.strided ? 2 : 1) : (g.pack2 ? 3 : 0), g.C8, g.nstages, g.N16, (unsigned short*)out, dgrad ? 0 : 1, g.kw,
+             g.pk_kw, g.pk_shift, d->kt * d->kh * d->kw);
   MD_CHECK_LAUNCH();
   return MD_OK;
 }
@@ -966,6 +1000,8 @@ struct WGeom {
   int N16;
   unsigned magicC8, magicNC;
   int off_y, off_rows, off_pixg, off_scale;
+  int pack2, pk_shift, pk_kw;   // pixel-pair reinterpretation (see wgrad_build); then kw = k-tiles per filter row
+  int tapw;                     // X patch bytes between successive values of the kw index
 };
 
 __device__ __forceinline__ bf16x8 tr_read2(const char* p0, const char* p1) {
@@ -997,7 +1033,7 @@ __global__ __launch_bounds__(256) void k_wgrad_patch(
   const int n0 = ng * g.nrep * 16;              // first dY channel of this workgroup
   const int kt0 = (kg * 4 + wave) * g.ktw;      // first k-tile of this wave
   const bool prologue = pscale != nullptr;
-  if (prologue) for (int c = t; c < g.Cpi; c += 256) { sScale[c] = pscale[c]; sShift[c] = pshift[c]; }
+  if (prologue) for (int c = t; c < g.Cpi; c += 256) { const int cs = g.pack2 ? (c & 3) : c; sScale[c] = pscale[cs]; sShift[c] = pshift[cs]; }
 
   f32x4 acc[KTW][NREP];
 #pragma unroll
@@ -1015,7 +1051,7 @@ __global__ __launch_bounds__(256) void k_wgrad_patch(
       const int tap = kt / g.KT; const int c16 = kt - tap * g.KT;
       const int dt = tap / g.khw; const int r = tap - dt * g.khw;
       const int dyy = r / g.kw; const int dxx = r - dyy * g.kw;
-      o = ((dt * g.py + dyy) * g.px + dxx) * g.ppitch + c16 * 32;
+      o = (dt * g.py + dyy) * g.px * g.ppitch + dxx * g.tapw + c16 * 32;
     }
     koff[a] = o;
   }
@@ -1107,7 +1143,7 @@ __global__ __launch_bounds__(256) void k_wgrad_patch(
 // budget allows for this kernel, so nothing else would overlap the loads.  All per-item index arithmetic that
 // does not depend on the box is done once.
 // ------------------------------------------------------------------------------------------------
-#define WPF_X 6
+#define WPF_X 7
 #define WPF_Y 5
 template <int KTW, int NREP>
 __global__ __launch_bounds__(256) void k_wgrad_patch_pf(
@@ -1129,7 +1165,7 @@ __global__ __launch_bounds__(256) void k_wgrad_patch_pf(
   const int n0 = ng * g.nrep * 16;
   const int kt0 = (kg * 4 + wave) * g.ktw;
   const bool prologue = pscale != nullptr;
-  if (prologue) for (int c = t; c < g.Cpi; c += 256) { sScale[c] = pscale[c]; sShift[c] = pshift[c]; }
+  if (prologue) for (int c = t; c < g.Cpi; c += 256) { const int cs = g.pack2 ? (c & 3) : c; sScale[c] = pscale[cs]; sShift[c] = pshift[cs]; }
   if (t < PM) {
     const int rt = t / g.byx; const int r = t - rt * g.byx;
     const int ry = r / g.bx; const int rx = r - ry * g.bx;
@@ -1150,7 +1186,7 @@ __global__ __launch_bounds__(256) void k_wgrad_patch_pf(
       const int tap = kt / g.KT; const int c16 = kt - tap * g.KT;
       const int dt = tap / g.khw; const int r = tap - dt * g.khw;
       const int dyy = r / g.kw; const int dxx = r - dyy * g.kw;
-      o = ((dt * g.py + dyy) * g.px + dxx) * g.ppitch + c16 * 32;
+      o = (dt * g.py + dyy) * g.px * g.ppitch + dxx * g.tapw + c16 * 32;
     }
     koff[a] = o;
   }
@@ -1313,8 +1349,10 @@ __global__ __launch_bounds__(256) void k_wgrad_patch_pf(
 
 // dw[cout][cin][tap] = sum_slices slab[slice][(tap*KT + cin/16)*16 + cin%16][cout]   (fixed order)
 // Block = 64 outputs x 4 slice groups: slice group q sums slices q, q+4, ... with four independent chains.
+// pack2: k-tile kt = (filter row, txg), row i of the tile = real tap dx = 4 txg + (i >> 2) + shift, channel i & 3.
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slab, int nslices, int nkt, int KT, int N16,
-                                                      int Cout, int Cin, int taps, float* __restrict__ dw) {
+                                                      int Cout, int Cin, int taps, float* __restrict__ dw, int pack2,
+                                                      int kwt, int kw_real, int shift, int taps_real) {
   __shared__ float red[4][64];
   const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int idx = blockIdx.x * 64 + o;                         // over [k16 rows][N16], cout fastest
@@ -1336,8 +1374,15 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
   if (q == 0 && idx < rows * N16) {
     const float s = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
     const int krow = idx / N16, co = idx - krow * N16;
-    const int kt = krow >> 4; const int tap = kt / KT; const int c = (kt - tap * KT) * 16 + (krow & 15);
-    if (co < Cout && c < Cin) dw[((size_t)co * Cin + c) * taps + tap] = s;
+    const int kt = krow >> 4;
+    if (pack2) {
+      const int row = kt / kwt, txg = kt - row * kwt, i = krow & 15;
+      const int dx = 4 * txg + (i >> 2) + shift, c = i & 3;
+      if (co < Cout && c < Cin && dx >= 0 && dx < kw_real) dw[((size_t)co * Cin + c) * taps_real + row * kw_real + dx] = s;
+    } else {
+      const int tap = kt / KT; const int c = (kt - tap * KT) * 16 + (krow & 15);
+      if (co < Cout && c < Cin) dw[((size_t)co * Cin + c) * taps + tap] = s;
+    }
   }
 }
 
@@ -1353,10 +1398,28 @@ static bool wgrad_build(const MdConvDesc* d, WGeom* out, size_t* lds_bytes, int*
   g.KT = md_cdiv(d->Cin, 16); g.nkt = g.taps * g.KT;
   g.C8i = 2 * g.KT;
   g.ppitch = pitch_for(g.C8i);
+  g.tapw = g.ppitch;
+  // Pixel-pair reinterpretation (see patch_build): the <= 4-channel, W-stride-2 input becomes [.., Wi/2][8] pairs with
+  // unit W-stride.  The patch is a dense array of 16-byte pairs, so one 16-channel k-tile spans two neighbouring pairs
+  // = 4 real pixels x 4 channels; kw counts k-tiles per filter row and the patch covers 2*kw pairs in x.
+  g.pack2 = 0; g.pk_shift = 0; g.pk_kw = d->kw;
+  static const int no_pack2 = getenv("MD_PACK2") && atoi(getenv("MD_PACK2")) == 0;
+  int kw_patch = d->kw;
+  if (!no_pack2 && g.Cpi == 4 && d->sw == 2 && (d->Wi & 1) == 0 && d->kw >= 2) {
+    const int lo = -((d->pw + 1) / 2);
+    const int num = d->kw - 1 - d->pw;
+    const int hi = num >= 0 ? num / 2 : -((-num + 1) / 2);
+    g.pack2 = 1; g.pk_shift = d->pw + 2 * lo;
+    g.kw = md_cdiv(hi - lo + 1, 2); g.khw = g.kh * g.kw; g.taps = d->kt * g.khw;
+    g.KT = 1; g.nkt = g.taps;
+    g.org_w = lo; g.sw = 1; g.Wi = d->Wi / 2; g.Cpi = 8; g.C8i = 1;
+    g.ppitch = 16; g.tapw = 32;
+    kw_patch = 2 * g.kw;
+  }
   g.N16 = md_round_up(d->Cout, 16);
   const int NT = g.N16 / 16;
   g.nng = md_cdiv(NT, WNR); g.nrep = md_cdiv(NT, g.nng);
-  g.ktw = md_cdiv(g.nkt, 4) <= 3 ? 3 : WKT;            // instantiated: 3 or 5 k-tiles per wave
+  { const int q = md_cdiv(g.nkt, 4); g.ktw = q <= 3 ? 3 : (q == 4 ? 4 : WKT); }     // instantiated: 3, 4 or 5 k-tiles per wave
   g.nkg = md_cdiv(g.nkt, 4 * g.ktw);
   g.NC = 2 * g.nrep;
   g.ypitch = pitch_for(g.NC);
@@ -1374,11 +1437,11 @@ static bool wgrad_build(const MdConvDesc* d, WGeom* out, size_t* lds_bytes, int*
   if (maxP > idx_cap) maxP = idx_cap;
   if (softP < 1) softP = 1;
   if (maxP < 1) return false;
-  if (!choose_box(g.To, g.Ho, g.Wo, d->kt, d->kh, d->kw, g.st, g.sh, g.sw, 0, (int)maxP, (int)softP, &g.bt, &g.by, &g.bx))
+  if (!choose_box(g.To, g.Ho, g.Wo, d->kt, d->kh, kw_patch, g.st, g.sh, g.sw, 0, (int)maxP, (int)softP, &g.bt, &g.by, &g.bx))
     return false;
   g.byx = g.by * g.bx;
   g.nbt = md_cdiv(g.To, g.bt); g.nby = md_cdiv(g.Ho, g.by); g.nbx = md_cdiv(g.Wo, g.bx);
-  g.pt = (g.bt - 1) * g.st + d->kt; g.py = (g.by - 1) * g.sh + d->kh; g.px = (g.bx - 1) * g.sw + d->kw;
+  g.pt = (g.bt - 1) * g.st + d->kt; g.py = (g.by - 1) * g.sh + d->kh; g.px = (g.bx - 1) * g.sw + kw_patch;
   g.pyx = g.py * g.px; g.P = g.pt * g.pyx;
   g.lo_off = (g.P * g.ppitch + 15) & ~15;
   g.nboxes = d->N * g.nbt * g.nby * g.nbx;
@@ -1450,11 +1513,11 @@ int wgrad_patch_launch(const WgradPlan* p, const MdConvDesc* d, const float* src
     case 4: LAUNCH_WG(KT_, 4); break;                                                                                   \
     default: LAUNCH_WG(KT_, 5); break;                                                                                  \
   }
-  if (g.ktw == 3) { LAUNCH_WG_NR(3); } else { LAUNCH_WG_NR(5); }
+  if (g.ktw == 3) { LAUNCH_WG_NR(3); } else if (g.ktw == 4) { LAUNCH_WG_NR(4); } else { LAUNCH_WG_NR(5); }
   MD_CHECK_LAUNCH();
   const int total = g.nkt * 16 * g.N16;
   MD_KLAUNCH(k_wgrad_reduce, dim3(md_cdiv(total, 64)), dim3(256), 0, s, slab, p->nslices, g.nkt, g.KT, g.N16, d->Cout,
-                     d->Cin, g.taps, dw);
+             d->Cin, g.taps, dw, g.pack2, g.kw, g.pk_kw, g.pk_shift, d->kt * d->kh * d->kw);
   MD_CHECK_LAUNCH();
   return MD_OK;
 }

@@ -49,6 +49,13 @@ CASES = [
     ("wide288", 128, 288, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 6, 6)),
     ("tmp288", 288, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 3, 4, 4)),
     ("full3d", 5, 9, (3, 3, 3), (2, 1, 2), (1, 1, 0), (2, 6, 7, 9)),   # general 3-D conv (SlowFast laterals use kt>1 strided)
+    # <= 4 input channels, W-stride 2, even width: the pixel-pair form of the patch kernels (every kw / pad parity)
+    ("pair3x3p1", 3, 20, (1, 3, 3), (1, 2, 2), (0, 1, 1), (2, 2, 10, 12)),
+    ("pair2x2p0", 4, 16, (1, 2, 2), (1, 2, 2), (0, 0, 0), (1, 3, 8, 14)),
+    ("pair5p2", 1, 33, (3, 5, 5), (1, 2, 2), (1, 2, 2), (2, 3, 9, 16)),
+    ("pair4p1w", 2, 7, (1, 3, 4), (1, 1, 2), (0, 1, 1), (2, 2, 7, 10)),
+    ("pair2p2", 3, 5, (1, 1, 2), (1, 1, 2), (0, 0, 2), (1, 2, 5, 8)),
+    ("pair7p0", 3, 45, (1, 7, 7), (1, 2, 2), (0, 3, 0), (1, 2, 20, 134)),
 ]
 
 

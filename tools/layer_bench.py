@@ -7,6 +7,8 @@ L = {
  'c1s': (32,72,(1,3,3),(1,1,1),(0,1,1),(8,21,64,64)),
  'c1t': (72,32,(3,1,1),(1,1,1),(1,0,0),(8,21,64,64)),
  'c3s': (64,144,(1,3,3),(1,1,1),(0,1,1),(8,11,32,32)),
+ 'stem': (3,45,(1,7,7),(1,2,2),(0,3,3),(8,21,128,128)),
+ 'c3d': (32,115,(1,3,3),(1,2,2),(0,1,1),(8,21,64,64)),
 }
 which = sys.argv[1:] or list(L)
 for name in which:

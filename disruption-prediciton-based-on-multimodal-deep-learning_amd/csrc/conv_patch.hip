@@ -47,7 +47,9 @@ struct PGeom {
   int Kc8;                  // taps * C8
   int nstages;              // ceil(Kc8 / 8): 64 k per stage
   int N16;
-  unsigned magicC8;         // floor(2^32 / C8) + 1 : exact item / C8 for item < 2^16
+  unsigned magicC8;         // floor(2^32 / C8) + 1 : exact item / C8 for item < 2^16 (0 when the divisor is 1)
+  unsigned m_pyx, m_px, m_byx, m_bx, m_khw, m_kw;   // same for the table decodes (all indices < 2^16)
+  unsigned src_bytes, dst_bytes;                      // tensor sizes for the buffer descriptors (< 4 GiB)
   int off_b, off_koffs, off_rows, off_pixg, off_scale;   // LDS byte offsets
   int pack2, pk_shift, pk_kw; // pixel-pair reinterpretation of a <=4-channel, W-stride-2 input (see patch_build)
 };
@@ -89,51 +91,60 @@ __device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
   lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
+// x / d for 0 <= x, x * d < 2^32, with magic = floor(2^32 / d) + 1 (0 encodes d == 1)
+__device__ __forceinline__ int mdiv(int x, unsigned magic) { return magic ? (int)__umulhi((unsigned)x, magic) : x; }
+
+// Raw buffer descriptor over a whole tensor (< 2 GiB): loads at an out-of-range offset return zeros and stores there
+// are dropped, so edge handling needs no branches and no 64-bit address arithmetic.  MD_OOB = 2 GiB is out of range
+// for every tensor we accept and cannot wrap around when an instruction offset is added.
+#define MD_OOB 0x80000000u
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  // (bit_cast of the whole vector: indexing the builtin's result element-wise is miscompiled into one dword load)
+  const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+  return make_float4(f[0], f[1], f[2], f[3]);
+}
+
 // Stage `npix` pixels x `C8` 8-channel chunks of a channels-last fp32 tensor into an LDS image
 // [pixel][C8 chunks] (pixel pitch `pitch` bytes; hi array at img, lo array at img + lo_off).
 // sG[pixel] = global pixel index or -1 (outside the tensor: zeros = the convolution's zero padding).
 // Channels c0 .. c0 + 4*cvalid4 are read (cvalid4 = valid float4 units from c0); chunks past that are zero.
 // With `prologue`, value = leaky(x*scale[c] + shift[c]) ("BN-on-read") before the bf16 hi/lo split.
 template <bool F16>
-__device__ __forceinline__ void stage_image(const float* __restrict__ src, int Cpitch, int c0, int cvalid4,
+__device__ __forceinline__ void stage_image(__amdgpu_buffer_rsrc_t src, int Cpitch, int c0, int cvalid4,
                                             const int* sG, int npix, int C8, unsigned magic, char* img, int pitch,
                                             int lo_off, bool prologue, const float* sScale, const float* sShift,
                                             float pslope, int t) {
   const int total = npix * C8;
   for (int base = 0; base < total; base += 256 * 4) {
     float4 va[4], vb[4];
-    int pix[4], c8s[4];
+    int pix[4], c8s[4];      // pix: pixel | 0x20000000 (outside the tensor: zeros, no prologue); -1 = no item
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int item = base + u * 256 + t;
-      va[u] = make_float4(0.f, 0.f, 0.f, 0.f); vb[u] = va[u];
-      pix[u] = -1; c8s[u] = 0;
-      if (item < total) {
-        const int pixel = magic ? (int)__umulhi((unsigned)item, magic) : item;
-        const int c8 = item - pixel * C8;
-        pix[u] = pixel | 0x20000000; c8s[u] = c8;        // 0x2..: nothing loaded (stays zero, no prologue)
-        const int gp = sG[pixel];
-        if (gp >= 0 && c8 * 2 < cvalid4) {
-          const float* s = src + (size_t)gp * Cpitch + c0 + c8 * 8;
-          va[u] = *(const float4*)s;
-          pix[u] = pixel;
-          if (c8 * 2 + 1 < cvalid4) vb[u] = *(const float4*)(s + 4);
-          else pix[u] |= 0x40000000;                       // upper half of the chunk is channel padding
-        }
-      }
+      const int item = min(base + u * 256 + t, total - 1);
+      const int pixel = mdiv(item, magic);
+      const int c8 = item - pixel * C8;
+      const int gp = sG[pixel];
+      const bool in = gp >= 0 && c8 * 2 < cvalid4;
+      const unsigned off = in ? (unsigned)(gp * Cpitch + c0 + c8 * 8) * 4u : MD_OOB;
+      va[u] = buf_load4(src, off);
+      vb[u] = buf_load4(src, (in && c8 * 2 + 1 < cvalid4) ? off + 16u : MD_OOB);
+      pix[u] = base + u * 256 + t < total ? (pixel | (in ? 0 : 0x20000000)) : -1;
+      c8s[u] = c8;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (pix[u] == -1) continue;
       const int pixel = pix[u] & 0x0fffffff;
-      const bool inside = !(pix[u] & 0x20000000);
-      const bool half = (pix[u] & 0x40000000) != 0;
       float v[8] = {va[u].x, va[u].y, va[u].z, va[u].w, vb[u].x, vb[u].y, vb[u].z, vb[u].w};
-      if (prologue && inside) {
+      if (prologue) {
+        const float keep = (pix[u] & 0x20000000) ? 0.f : 1.f;       // padding stays zero after the activation
         const float* sc = sScale + c0 + c8s[u] * 8; const float* sh = sShift + c0 + c8s[u] * 8;
+        const int nv = min(8, (cvalid4 - c8s[u] * 2) * 4);          // channels of this chunk that exist
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = md_leaky(fmaf(v[e], sc[e], sh[e]), pslope);
-        if (half) { v[4] = v[5] = v[6] = v[7] = 0.f; }
+        for (int e = 0; e < 8; ++e) v[e] = e < nv ? md_leaky(fmaf(v[e], sc[e], sh[e]), pslope) * keep : 0.f;
       }
       uint4 hi, lo;
       if (F16) split8_f16(v, hi, lo); else split8(v, hi, lo);
@@ -172,7 +183,7 @@ __global__ __launch_bounds__(256) void k_conv_patch(
   const int n0 = blockIdx.y * n_per_blk;
   const int ncols = min(n_per_blk, g.N16 - n0);
   const bool prologue = pscale != nullptr;
-  const int dbg = accumulate >> 8;      // timing experiments (MD_DBG): 1 skip patch loads, 2 skip MFMA loop, 4 skip stores
+  const int dbg = (accumulate >> 8) & 0xff;      // timing experiments (MD_DBG): 1 skip patch loads, 2 skip MFMA loop, 4 skip stores
   accumulate &= 1;
 
   // ---- which box
@@ -195,8 +206,8 @@ __global__ __launch_bounds__(256) void k_conv_patch(
 
   // ---- tables
   for (int p = t; p < g.P; p += 256) {
-    const int ppt = p / g.pyx; const int r = p - ppt * g.pyx;
-    const int ppy = r / g.px; const int ppx = r - ppy * g.px;
+    const int ppt = mdiv(p, g.m_pyx); const int r = p - ppt * g.pyx;
+    const int ppy = mdiv(r, g.m_px); const int ppx = r - ppy * g.px;
     int st, sy, sx;
     if (STRIDED) { st = po_t + ppt; sy = po_h + ppy; sx = po_w + ppx; }
     else { st = t0 * g.st + g.org_t + ppt; sy = y0 * g.sh + g.org_h + ppy; sx = x0 * g.sw + g.org_w + ppx; }
@@ -204,8 +215,8 @@ __global__ __launch_bounds__(256) void k_conv_patch(
     sG[p] = v ? ((n * g.Ts + st) * g.Hs + sy) * g.Ws + sx : -1;
   }
   if (t < PM) {
-    const int rt = t / g.byx; const int r = t - rt * g.byx;
-    const int ry = r / g.bx; const int rx = r - ry * g.bx;
+    const int rt = mdiv(t, g.m_byx); const int r = t - rt * g.byx;
+    const int ry = mdiv(r, g.m_bx); const int rx = r - ry * g.bx;
     const bool v = (rt < g.bt) && (t0 + rt < g.Td) && (y0 + ry < g.Hd) && (x0 + rx < g.Wd);
     int4 ri;
     ri.x = v ? ((rt * g.st * g.py + ry * g.sh) * g.px + rx * g.sw) * g.ppitch : 0;
@@ -217,9 +228,9 @@ __global__ __launch_bounds__(256) void k_conv_patch(
   for (int q = t; q < g.nstages * 8; q += 256) {
     int ko = STRIDED ? -1 : 0;              // strided: -1 marks a K-padding chunk (reads the zero pixel)
     if (q < g.Kc8) {
-      const int tap = q / g.C8; const int c8 = q - tap * g.C8;
-      const int dt = tap / g.khw; const int r = tap - dt * g.khw;
-      const int dy = r / g.kw; const int dx = r - dy * g.kw;
+      const int tap = mdiv(q, g.magicC8); const int c8 = q - tap * g.C8;
+      const int dt = mdiv(tap, g.m_khw); const int r = tap - dt * g.khw;
+      const int dy = mdiv(r, g.m_kw); const int dx = r - dy * g.kw;
       if (STRIDED) ko = dt | (dy << 8) | (dx << 16) | (c8 << 24);
       else ko = ((dt * g.py + dy) * g.px + dx) * g.ppitch + c8 * 16;
     }
@@ -227,17 +238,20 @@ __global__ __launch_bounds__(256) void k_conv_patch(
   }
   if (prologue) for (int c = t; c < g.Cps; c += 256) { const int cs = g.pack2 ? (c & 3) : c; sScale[c] = pscale[cs]; sShift[c] = pshift[cs]; }
 
-  // ---- B tile prefetch (registers): [stage][hi|lo][N16][8 chunks] uint4, this block's rows n0..n0+ncols
+  // ---- B tile prefetch (registers): [stage][hi|lo][N16][8 chunks] uint4, this block's rows n0..n0+ncols.
+  // Loads are unconditional (clamped index) so that the prefetch stays a straight run of global loads.
   const int bchunks = ncols * 8;                 // per half
-  uint4 rb[2][5];                                // up to 144*8/256 = 4.5 chunks per thread per half
+  constexpr int NB = (NREP + 1) / 2;             // 16-byte chunks per thread per half (NREP*16*8 / 256)
+  uint4 rb[2][NB];
   auto load_b = [&](int kb) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const uint4* base = wp + ((size_t)(kb * 2 + h) * g.N16 + n0) * 8;
 #pragma unroll
-      for (int i = 0; i < 5; ++i) {
+      for (int i = 0; i < NB; ++i) {
         const int c = t + 256 * i;
-        rb[h][i] = c < bchunks ? base[c] : make_uint4(0, 0, 0, 0);
+        const uint4 v = base[min(c, bchunks - 1)];     // columns past ncols get copies of a valid one; never stored
+        rb[h][i] = v;
       }
     }
   };
@@ -246,7 +260,8 @@ __global__ __launch_bounds__(256) void k_conv_patch(
 
   // ---- stage the patch: global 32 B per lane -> (BN+act) -> split -> 16 B hi + 16 B lo
   if (!(dbg & 1))
-    stage_image<F16>(src, g.Cps, 0, g.Cps >> 2, sG, g.P, g.C8, g.magicC8, sP, g.ppitch, g.lo_off, prologue, sScale, sShift, pslope, t);
+    stage_image<F16>(make_rsrc(src, g.src_bytes), g.Cps, 0, g.Cps >> 2, sG, g.P, g.C8, g.magicC8, sP, g.ppitch, g.lo_off, prologue, sScale,
+                     sShift, pslope, t);
   if (STRIDED) {
     for (int i = t * 16; i < g.ppitch; i += 256 * 16) {
       *(uint4*)(sP + g.zero_off + i) = make_uint4(0, 0, 0, 0);
@@ -272,76 +287,119 @@ __global__ __launch_bounds__(256) void k_conv_patch(
     for (int j = 0; j < NREP; ++j) acc[a][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int blo = n_per_blk * PB_PITCH;    // lo half of the B tile
-  for (int kb = 0; kb < ((dbg & 2) ? 0 : g.nstages); ++kb) {
-    __syncthreads();                       // patch staged (first iteration) / previous B tile consumed
+  // Software pipeline over the k32 steps (two per 64-k stage): the A fragments of step q+1 (they live in the patch,
+  // which does not change during the loop) are requested at the start of step q, and inside a stage the B fragments
+  // of column tile j+1 are requested before the six MFMAs of tile j, so LDS latency hides behind the matrix pipe.
+  const int nsteps = ((dbg & 2) ? 0 : g.nstages) * 2;
+  uint4 fa[2][4];                          // [step parity][hi0, lo0, hi1, lo1]
+  auto a_offsets = [&](int ko, int& o0, int& o1) {
+    o0 = STRIDED ? strided_off(rc0, ko) : rp0 + ko;
+    o1 = STRIDED ? strided_off(rc1, ko) : rp1 + ko;
+  };
+  auto load_a = [&](int o0, int o1, uint4* f) {
+    f[0] = *(const uint4*)(sP + o0); f[1] = *(const uint4*)(sP + g.lo_off + o0);
+    f[2] = *(const uint4*)(sP + o1); f[3] = *(const uint4*)(sP + g.lo_off + o1);
+  };
+  const char* bbase = sB + li * PB_PITCH + lg * 16;
+  int ko_next = 0;                         // K offset of step q+1 while step q runs
+  if (nsteps) {
+    __syncthreads();                       // patch staged
+    int o0, o1;
+    a_offsets(sK[lg], o0, o1);
+    load_a(o0, o1, fa[0]);
+    ko_next = sK[4 + lg];                  // nsteps >= 2
+  }
+  for (int kb = 0; kb * 2 < nsteps; ++kb) {
+    __syncthreads();                       // previous B tile consumed
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int i = 0; i < 5; ++i) {
+      for (int i = 0; i < NB; ++i) {
         const int c = t + 256 * i;
         if (c < n_per_blk * 8 && !((dbg & 16) && kb > 0)) *(uint4*)(sB + h * blo + (c >> 3) * PB_PITCH + (c & 7) * 16) = rb[h][i];
       }
     __syncthreads();
     if (kb + 1 < g.nstages && !(dbg & 32)) load_b(kb + 1);
+    uint4 fb[2][2];                        // [buffer][hi, lo]
+    fb[0][0] = *(const uint4*)bbase; fb[0][1] = *(const uint4*)(bbase + blo);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const int ko = sK[kb * 8 + s * 4 + lg];
-      const int o0 = STRIDED ? strided_off(rc0, ko) : rp0 + ko;
-      const int o1 = STRIDED ? strided_off(rc1, ko) : rp1 + ko;
-      const uint4 ah0 = *(const uint4*)(sP + o0), al0 = *(const uint4*)(sP + g.lo_off + o0);
-      const uint4 ah1 = *(const uint4*)(sP + o1), al1 = *(const uint4*)(sP + g.lo_off + o1);
+      {   // A fragments of the next step (the last step re-reads its own: branch-free), K offset of the one after
+        int o0, o1;
+        a_offsets(ko_next, o0, o1);
+        load_a(o0, o1, fa[s ^ 1]);
+        ko_next = sK[min(kb * 2 + s + 2, nsteps - 1) * 4 + lg];
+      }
+      const uint4 ah0 = fa[s][0], al0 = fa[s][1], ah1 = fa[s][2], al1 = fa[s][3];
 #pragma unroll
       for (int j = 0; j < NREP; ++j) {
-        {
-          const char* bp = sB + (j * 16 + li) * PB_PITCH + (s * 4 + lg) * 16;
-          const uint4 bh = *(const uint4*)bp, bl = *(const uint4*)(bp + blo);
-          // smallest terms first: lo*hi and hi*lo, then hi*hi
-          acc[0][j] = mma<F16>(al0, bh, acc[0][j]);
-          acc[1][j] = mma<F16>(al1, bh, acc[1][j]);
-          acc[0][j] = mma<F16>(ah0, bl, acc[0][j]);
-          acc[1][j] = mma<F16>(ah1, bl, acc[1][j]);
-          acc[0][j] = mma<F16>(ah0, bh, acc[0][j]);
-          acc[1][j] = mma<F16>(ah1, bh, acc[1][j]);
+        const int cur = (s * NREP + j) & 1;
+        const bool more = j + 1 < NREP || s == 0;      // next column tile (of this step, or tile 0 of the second step)
+        if (more) {
+          const int jn = j + 1 < NREP ? j + 1 : 0, sn = j + 1 < NREP ? s : 1;
+          const char* bp = bbase + jn * 16 * PB_PITCH + sn * 64;
+          fb[cur ^ 1][0] = *(const uint4*)bp; fb[cur ^ 1][1] = *(const uint4*)(bp + blo);
         }
+        const uint4 bh = fb[cur][0], bl = fb[cur][1];
+        // smallest terms first: lo*hi and hi*lo, then hi*hi
+        acc[0][j] = mma<F16>(al0, bh, acc[0][j]);
+        acc[1][j] = mma<F16>(al1, bh, acc[1][j]);
+        acc[0][j] = mma<F16>(ah0, bl, acc[0][j]);
+        acc[1][j] = mma<F16>(ah1, bl, acc[1][j]);
+        acc[0][j] = mma<F16>(ah0, bh, acc[0][j]);
+        acc[1][j] = mma<F16>(ah1, bh, acc[1][j]);
+        // keep the issue order: this tile's LDS requests, then its six MFMAs
+        if (j == 0 && more) __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
+        else if (j == 0) __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+        else if (more) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
       }
     }
   }
 
-  // ---- epilogue: store + BatchNorm partial sums over VALID rows
-  int gix[2][4];
+  // ---- epilogue: store + BatchNorm partial sums over VALID rows.  Rows outside the tensor get the out-of-range
+  // buffer offset (store dropped) and weight 0 in the sums; no branches.
+  unsigned goff[2][4];
+  float gw[2][4];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) gix[a][r] = sR[wave * 32 + a * 16 + lg * 4 + r].y;
+    for (int r = 0; r < 4; ++r) {
+      const int gi = sR[wave * 32 + a * 16 + lg * 4 + r].y;
+      goff[a][r] = gi >= 0 ? (unsigned)(gi * g.Cpd + n0 + li) * 4u : MD_OOB;
+      gw[a][r] = gi >= 0 ? 1.f : 0.f;
+    }
   __syncthreads();
   float* red = (float*)sP;   // [4 waves][2][PNREP*16]
+  const __amdgpu_buffer_rsrc_t drs = make_rsrc(dst, (dbg & 4) ? 0u : g.dst_bytes);
 #pragma unroll
   for (int j = 0; j < NREP; ++j) {
-    {
-      const int col = n0 + j * 16 + li;
-      float s1 = 0.f, s2 = 0.f;
+    const bool colok = n0 + j * 16 + li < g.Cpd;
+    float s1 = 0.f, s2 = 0.f;
+    float prev[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (accumulate) {
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int gi = gix[a][r];
-          if (gi >= 0) {
-            float v = acc[a][j][r];
-            s1 += v; s2 = fmaf(v, v, s2);
-            if (col < g.Cpd && !(dbg & 4)) {
-              float* p = dst + (size_t)gi * g.Cpd + col;
-              if (accumulate) v += *p;
-              *p = v;
-            }
-          }
-        }
-      if (stat_partial != nullptr) {
-        s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
-        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-        if (lg == 0) {
-          red[(wave * 2 + 0) * (PNREP * 16) + j * 16 + li] = s1;
-          red[(wave * 2 + 1) * (PNREP * 16) + j * 16 + li] = s2;
-        }
+        for (int r = 0; r < 4; ++r)
+          prev[a][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, colok ? goff[a][r] : MD_OOB, j * 64, 0));
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = acc[a][j][r];
+        const float vm = v * gw[a][r];
+        s1 += vm; s2 = fmaf(vm, v, s2);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v + prev[a][r]), drs, colok ? goff[a][r] : MD_OOB, j * 64, 0);
+      }
+    if (stat_partial != nullptr) {
+      s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+      s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+      if (lg == 0) {
+        red[(wave * 2 + 0) * (PNREP * 16) + j * 16 + li] = s1;
+        red[(wave * 2 + 1) * (PNREP * 16) + j * 16 + li] = s2;
       }
     }
   }
@@ -357,253 +415,6 @@ __global__ __launch_bounds__(256) void k_conv_patch(
       float* sp = stat_partial + (size_t)blockIdx.x * 2 * g.Cpd;
       sp[n0 + t] = s1;
       sp[g.Cpd + n0 + t] = s2;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Persistent, software-pipelined variant of k_conv_patch (same arithmetic, same results).  A workgroup walks boxes
-// blockIdx.x, blockIdx.x + gridDim.x, ...; the global loads of the NEXT box's patch are issued into registers before
-// the current box's K loop and committed (BN-on-read, hi/lo split, LDS write) after its epilogue, so HBM latency and
-// the per-box set-up overlap the matrix work instead of preceding it.  Everything that does not depend on the box
-// (K-offset table, row offsets, item decode) is computed once per workgroup.  Used when the patch fits
-// PP_ITEMS x 256 items and the strided data-gradient form is not needed.
-// ------------------------------------------------------------------------------------------------
-template <bool F16, int NREP, int PP_ITEMS>
-__global__ __launch_bounds__(256, 2) void k_conv_patch_pp(
-    PGeom g, const float* __restrict__ src, const float* __restrict__ pscale, const float* __restrict__ pshift,
-    float pslope, const uint4* __restrict__ wp, float* __restrict__ dst, float* __restrict__ stat_partial,
-    int accumulate, int n_per_blk, int nboxes) {
-  extern __shared__ __attribute__((aligned(16))) char sm[];
-  char* sP = sm;
-  char* sB = sm + g.off_b;
-  int* sK = (int*)(sm + g.off_koffs);
-  float* sRed = (float*)(sm + g.off_rows);         // [4 waves][2][PNREP*16] epilogue reduction (4.6 KB <= rows+pixg area)
-  float* sScale = (float*)(sm + g.off_scale);
-  float* sShift = sScale + PMAXC;
-
-  const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
-  const int li = lane & 15, lg = lane >> 4;
-  const int n0 = blockIdx.y * n_per_blk;
-  const int ncols = min(n_per_blk, g.N16 - n0);
-  const bool prologue = pscale != nullptr;
-  const int dbg = accumulate >> 8;   // timing experiments: 1 no commit, 2 no K loop, 4 no stores, 8 no loads
-  accumulate &= 1;
-
-  for (int q = t; q < g.nstages * 8; q += 256) {
-    int ko = 0;
-    if (q < g.Kc8) {
-      const int tap = q / g.C8; const int c8 = q - tap * g.C8;
-      const int dt = tap / g.khw; const int r = tap - dt * g.khw;
-      const int dy = r / g.kw; const int dx = r - dy * g.kw;
-      ko = ((dt * g.py + dy) * g.px + dx) * g.ppitch + c8 * 16;
-    }
-    sK[q] = ko;
-  }
-  if (prologue) for (int c = t; c < g.Cps; c += 256) { const int cs = g.pack2 ? (c & 3) : c; sScale[c] = pscale[cs]; sShift[c] = pshift[cs]; }
-
-  // rows of this lane: A-fragment rows (wave*32 + {0,16} + li) and accumulator rows (wave*32 + a*16 + 4*lg + r)
-  auto row_local = [&](int row, int& rt, int& ry, int& rx) {
-    rt = row / g.byx; const int r = row - rt * g.byx; ry = r / g.bx; rx = r - ry * g.bx;
-  };
-  int rp0, rp1;
-  {
-    int rt, ry, rx;
-    row_local(wave * 32 + li, rt, ry, rx);
-    rp0 = rt < g.bt ? ((rt * g.st * g.py + ry * g.sh) * g.px + rx * g.sw) * g.ppitch : 0;
-    row_local(wave * 32 + 16 + li, rt, ry, rx);
-    rp1 = rt < g.bt ? ((rt * g.st * g.py + ry * g.sh) * g.px + rx * g.sw) * g.ppitch : 0;
-  }
-  int orow[2][4];      // packed local coords of the accumulator rows (rt | ry<<6 | rx<<15), -1 outside the box
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      int rt, ry, rx;
-      row_local(wave * 32 + a * 16 + lg * 4 + r, rt, ry, rx);
-      orow[a][r] = rt < g.bt ? (rt | (ry << 6) | (rx << 15)) : -1;
-    }
-
-  // box-independent decode of this thread's patch items
-  const int total = g.P * g.C8;
-  const int cv4 = g.Cps >> 2;
-  int iloc[PP_ITEMS], idst[PP_ITEMS];
-#pragma unroll
-  for (int u = 0; u < PP_ITEMS; ++u) {
-    const int item = u * 256 + t;
-    idst[u] = -1; iloc[u] = 0;
-    if (item < total) {
-      const int pixel = g.magicC8 ? (int)__umulhi((unsigned)item, g.magicC8) : item;
-      const int c8 = item - pixel * g.C8;
-      const int ppt = pixel / g.pyx; const int r = pixel - ppt * g.pyx;
-      const int ppy = r / g.px; const int ppx = r - ppy * g.px;
-      iloc[u] = ppt | (ppy << 6) | (ppx << 15) | (c8 << 24);
-      idst[u] = pixel * g.ppitch + c8 * 16;
-    }
-  }
-  float4 va[PP_ITEMS], vb[PP_ITEMS];
-  int fl = 0;
-  auto box_origin = [&](int box, int& n, int& t0, int& y0, int& x0) {
-    int b = box;
-    const int xb = b % g.nbx; b /= g.nbx;
-    const int yb = b % g.nby; b /= g.nby;
-    const int tb = b % g.nbt; n = b / g.nbt;
-    t0 = tb * g.bt; y0 = yb * g.by; x0 = xb * g.bx;
-  };
-  auto issue = [&](int box) {
-    int n, t0, y0, x0;
-    box_origin(box, n, t0, y0, x0);
-    const int ot = t0 * g.st + g.org_t, oh = y0 * g.sh + g.org_h, ow = x0 * g.sw + g.org_w;
-    fl = 0;
-#pragma unroll
-    for (int u = 0; u < PP_ITEMS; ++u) {
-      va[u] = make_float4(0.f, 0.f, 0.f, 0.f); vb[u] = va[u];
-      if (idst[u] >= 0) {
-        const int st = ot + (iloc[u] & 63), sy = oh + ((iloc[u] >> 6) & 511), sx = ow + ((iloc[u] >> 15) & 511);
-        const int c8 = (iloc[u] >> 24) & 255;
-        if (((unsigned)st < (unsigned)g.Ts) && ((unsigned)sy < (unsigned)g.Hs) && ((unsigned)sx < (unsigned)g.Ws) &&
-            c8 * 2 < cv4) {
-          const float* s = src + ((size_t)((n * g.Ts + st) * g.Hs + sy) * g.Ws + sx) * g.Cps + c8 * 8;
-          va[u] = *(const float4*)s;
-          fl |= 1 << (2 * u);
-          if (c8 * 2 + 1 < cv4) vb[u] = *(const float4*)(s + 4); else fl |= 2 << (2 * u);
-        }
-      }
-    }
-  };
-  auto commit = [&]() {
-#pragma unroll
-    for (int u = 0; u < PP_ITEMS; ++u) {
-      if (idst[u] >= 0) {
-        float v[8] = {va[u].x, va[u].y, va[u].z, va[u].w, vb[u].x, vb[u].y, vb[u].z, vb[u].w};
-        if (prologue && ((fl >> (2 * u)) & 1)) {
-          const int c8 = (iloc[u] >> 24) & 255;
-          const float* sc = sScale + c8 * 8; const float* sh = sShift + c8 * 8;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = md_leaky(fmaf(v[e], sc[e], sh[e]), pslope);
-          if ((fl >> (2 * u)) & 2) { v[4] = v[5] = v[6] = v[7] = 0.f; }
-        }
-        uint4 hi, lo;
-        if (F16) split8_f16(v, hi, lo); else split8(v, hi, lo);
-        *(uint4*)(sP + idst[u]) = hi;
-        *(uint4*)(sP + g.lo_off + idst[u]) = lo;
-      }
-    }
-  };
-
-  const int bchunks = ncols * 8;
-  uint4 rb[2][5];
-  auto load_b = [&](int kb) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const uint4* base = wp + ((size_t)(kb * 2 + h) * g.N16 + n0) * 8;
-#pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        const int c = t + 256 * i;
-        rb[h][i] = c < bchunks ? base[c] : make_uint4(0, 0, 0, 0);
-      }
-    }
-  };
-  const int blo = n_per_blk * PB_PITCH;
-
-  int box = blockIdx.x;
-  if (box < nboxes && !(dbg & 8)) issue(box);
-  for (; box < nboxes; box += gridDim.x) {
-    __syncthreads();                      // previous box: K loop and epilogue reduction done (first: tables in LDS)
-    if (!(dbg & 1)) commit();
-    load_b(0);
-    const int nxt = box + gridDim.x;
-    if (nxt < nboxes && !(dbg & 8)) issue(nxt);         // next box's patch loads stay in flight during the K loop
-
-    f32x4 acc[2][NREP];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int j = 0; j < NREP; ++j) acc[a][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int kb = 0; kb < ((dbg & 2) ? 0 : g.nstages); ++kb) {
-      __syncthreads();                    // patch committed (first stage) / previous B tile consumed
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-          const int c = t + 256 * i;
-          if (c < n_per_blk * 8) *(uint4*)(sB + h * blo + (c >> 3) * PB_PITCH + (c & 7) * 16) = rb[h][i];
-        }
-      __syncthreads();
-      if (kb + 1 < g.nstages) load_b(kb + 1);
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int ko = sK[kb * 8 + s * 4 + lg];
-        const uint4 ah0 = *(const uint4*)(sP + rp0 + ko), al0 = *(const uint4*)(sP + g.lo_off + rp0 + ko);
-        const uint4 ah1 = *(const uint4*)(sP + rp1 + ko), al1 = *(const uint4*)(sP + g.lo_off + rp1 + ko);
-#pragma unroll
-        for (int j = 0; j < NREP; ++j) {
-          const char* bp = sB + (j * 16 + li) * PB_PITCH + (s * 4 + lg) * 16;
-          const uint4 bh = *(const uint4*)bp, bl = *(const uint4*)(bp + blo);
-          acc[0][j] = mma<F16>(al0, bh, acc[0][j]);
-          acc[1][j] = mma<F16>(al1, bh, acc[1][j]);
-          acc[0][j] = mma<F16>(ah0, bl, acc[0][j]);
-          acc[1][j] = mma<F16>(ah1, bl, acc[1][j]);
-          acc[0][j] = mma<F16>(ah0, bh, acc[0][j]);
-          acc[1][j] = mma<F16>(ah1, bh, acc[1][j]);
-        }
-      }
-    }
-
-    // ---- epilogue
-    int n, t0, y0, x0;
-    box_origin(box, n, t0, y0, x0);
-    int gix[2][4];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int oc = orow[a][r];
-        const int ot = t0 + (oc & 63), oy = y0 + ((oc >> 6) & 511), ox = x0 + ((oc >> 15) & 511);
-        gix[a][r] = (oc >= 0 && ot < g.Td && oy < g.Hd && ox < g.Wd) ? ((n * g.Td + ot) * g.Hd + oy) * g.Wd + ox : -1;
-      }
-#pragma unroll
-    for (int j = 0; j < NREP; ++j) {
-      const int col = n0 + j * 16 + li;
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int gi = gix[a][r];
-          if (gi >= 0) {
-            float v = acc[a][j][r];
-            s1 += v; s2 = fmaf(v, v, s2);
-            if (col < g.Cpd && !(dbg & 4)) {
-              float* p = dst + (size_t)gi * g.Cpd + col;
-              if (accumulate) v += *p;
-              *p = v;
-            }
-          }
-        }
-      if (stat_partial != nullptr) {
-        s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
-        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-        if (lg == 0) {
-          sRed[(wave * 2 + 0) * (PNREP * 16) + j * 16 + li] = s1;
-          sRed[(wave * 2 + 1) * (PNREP * 16) + j * 16 + li] = s2;
-        }
-      }
-    }
-    if (stat_partial != nullptr) {
-      __syncthreads();
-      if (t < ncols && n0 + t < g.Cpd) {
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          s1 += sRed[(w * 2 + 0) * (PNREP * 16) + t];
-          s2 += sRed[(w * 2 + 1) * (PNREP * 16) + t];
-        }
-        float* sp = stat_partial + (size_t)box * 2 * g.Cpd;
-        sp[n0 + t] = s1;
-        sp[g.Cpd + n0 + t] = s2;
-      }
     }
   }
 }
@@ -696,6 +507,7 @@ static bool choose_box(int T, int H, int W, int kt, int kh, int kw, int st, int 
   return found;
 }
 
+static unsigned magic_of(int d) { return d <= 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)d) + 1u; }
 static int ilog2_exact(int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; }
 
 static bool patch_build(const MdConvDesc* d, int dgrad, PGeom* out, size_t* lds_bytes) {
@@ -735,7 +547,13 @@ static bool patch_build(const MdConvDesc* d, int dgrad, PGeom* out, size_t* lds_
   g.Kc8 = g.taps * g.C8;
   g.nstages = md_cdiv(g.Kc8, 8);
   g.N16 = md_round_up(cd, 16);
-  g.magicC8 = g.C8 == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)g.C8) + 1u;
+  g.magicC8 = magic_of(g.C8);
+  {
+    const unsigned long long sb = (unsigned long long)d->N * g.Ts * g.Hs * g.Ws * g.Cps * 4ull;
+    const unsigned long long db = (unsigned long long)d->N * g.Td * g.Hd * g.Wd * g.Cpd * 4ull;
+    if (sb >= 0x80000000ull || db >= 0x80000000ull) return false;     // buffer addressing: 2 GiB per tensor
+    g.src_bytes = (unsigned)sb; g.dst_bytes = (unsigned)db;
+  }
   if (g.Cps > PMAXC) return false;
   const int nchunks_ = md_cdiv(g.N16, PNREP * 16);
   const int npb_ = md_round_up(md_cdiv(g.N16, nchunks_), 16);
@@ -761,6 +579,8 @@ static bool patch_build(const MdConvDesc* d, int dgrad, PGeom* out, size_t* lds_
     g.pt = (g.bt + d->kt - 2) / d->st + 2; g.py = (g.by + d->kh - 2) / d->sh + 2; g.px = (g.bx + d->kw - 2) / d->sw + 2;
   }
   g.pyx = g.py * g.px; g.P = g.pt * g.pyx;
+  g.m_pyx = magic_of(g.pyx); g.m_px = magic_of(g.px); g.m_byx = magic_of(g.byx); g.m_bx = magic_of(g.bx);
+  g.m_khw = magic_of(g.khw); g.m_kw = magic_of(g.kw);
   g.zero_off = g.P * g.ppitch;                          // one all-zero pixel behind the patch (invalid taps read it)
   g.lo_off = ((g.P + 1) * g.ppitch + 15) & ~15;
   size_t off = (size_t)2 * g.lo_off;
@@ -889,7 +709,7 @@ int patch_launch(const PatchPlan* p, const float* src, const float* ps, const fl
   const int npb = md_round_up(md_cdiv(g.N16, nchunks), 16);
   dim3 grid(patch_blocks(p), md_cdiv(g.N16, npb));
   static const int dbg = getenv("MD_DBG") ? atoi(getenv("MD_DBG")) : 0;
-  accumulate = (accumulate & 1) | (dbg << 8);
+  accumulate = (accumulate & 1) | ((dbg & 0xff) << 8);
   const int nrep = npb / 16;
 #define LAUNCH_PATCH(F16_, STR_, NR_)                                                                                   \
   do {                                                                                                                  \
@@ -914,59 +734,69 @@ int patch_launch(const PatchPlan* p, const float* src, const float* ps, const fl
     case 8: LAUNCH_PATCH(F16_, STR_, 8); break;                                                                         \
     default: LAUNCH_PATCH(F16_, STR_, 9); break;                                                                        \
   }
-  // persistent pipelined variant: the patch must fit the register prefetch (3 or 7 items of 32 B per thread; 7 only
-  // with <= 4 column tiles, beyond that the register file spills) and the coordinate packing
-  // Opt-in (MD_PATCH_PP=1): measured neutral on MI355X (c1s 188 -> 181 us, c1t 132 -> 137 us) because a wave's vector
-  // memory operations retire in order: the first B-tile wait of the K loop also waits for the prefetched patch.
-  static const int no_pp = !(getenv("MD_PATCH_PP") && atoi(getenv("MD_PATCH_PP")) == 1);
-  const int nboxes = patch_blocks(p);
-  const int items = md_cdiv(g.P * g.C8, 256);
-  const bool pp = !no_pp && !g.strided && (items <= 3 || (items <= 7 && nrep <= 4)) && g.pt < 64 && g.py < 512 &&
-                  g.px < 512 && g.bt < 64;
-  if (pp) {
-    int wgs = 2 * 256;                            // two workgroups per CU stay resident (LDS-limited)
-    if (wgs > nboxes) wgs = nboxes;
-    dim3 pgrid(wgs, grid.y);
-#define LAUNCH_PP(F16_, NR_, IT_)                                                                                       \
-  do {                                                                                                                  \
-    static bool set_ = false;                                                                                           \
-    if (!set_) {                                                                                                        \
-      if (hipFuncSetAttribute((const void*)k_conv_patch_pp<F16_, NR_, IT_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              160 * 1024) != hipSuccess) return MD_ERR_LAUNCH;                                          \
-      set_ = true;                                                                                                      \
-    }                                                                                                                   \
-    MD_KLAUNCH((k_conv_patch_pp<F16_, NR_, IT_>), pgrid, dim3(256), p->lds, s, g, src, ps, psh, slope,          \
-                       (const uint4*)wp, dst, stat, accumulate, npb, nboxes);                                           \
-  } while (0)
-#define LAUNCH_PP_NR(F16_)                                                                                              \
-  if (items <= 3) {                                                                                                     \
-    switch (nrep) {                                                                                                     \
-      case 1: LAUNCH_PP(F16_, 1, 3); break;                                                                             \
-      case 2: LAUNCH_PP(F16_, 2, 3); break;                                                                             \
-      case 3: LAUNCH_PP(F16_, 3, 3); break;                                                                             \
-      case 4: LAUNCH_PP(F16_, 4, 3); break;                                                                             \
-      case 5: LAUNCH_PP(F16_, 5, 3); break;                                                                             \
-      case 6: LAUNCH_PP(F16_, 6, 3); break;                                                                             \
-      case 7: LAUNCH_PP(F16_, 7, 3); break;                                                                             \
-      case 8: LAUNCH_PP(F16_, 8, 3); break;                                                                             \
-      default: LAUNCH_PP(F16_, 9, 3); break;                                                                            \
-    }                                                                                                                   \
-  } else {                                                                                                              \
-    switch (nrep) {                                                                                                     \
-      case 1: LAUNCH_PP(F16_, 1, 7); break;                                                                             \
-      case 2: LAUNCH_PP(F16_, 2, 7); break;                                                                             \
-      case 3: LAUNCH_PP(F16_, 3, 7); break;                                                                             \
-      default: LAUNCH_PP(F16_, 4, 7); break;                                                                            \
-    }                                                                                                                   \
-  }
-    if (!p->dgrad) { LAUNCH_PP_NR(true); } else { LAUNCH_PP_NR(false); }
-  }
-  else if (!p->dgrad) { LAUNCH_PATCH_NR(true, false); }
+  if (!p->dgrad) { LAUNCH_PATCH_NR(true, false); }
   else if (!g.strided) { LAUNCH_PATCH_NR(false, false); }
   else { LAUNCH_PATCH_NR(false, true); }
   MD_CHECK_LAUNCH();
   return MD_OK;
 }
+
+// Pointer-based variant (branches around the edge cases) kept for the weight-gradient kernels, where it measured faster.
+// Stage `npix` pixels x `C8` 8-channel chunks of a channels-last fp32 tensor into an LDS image
+// [pixel][C8 chunks] (pixel pitch `pitch` bytes; hi array at img, lo array at img + lo_off).
+// sG[pixel] = global pixel index or -1 (outside the tensor: zeros = the convolution's zero padding).
+// Channels c0 .. c0 + 4*cvalid4 are read (cvalid4 = valid float4 units from c0); chunks past that are zero.
+// With `prologue`, value = leaky(x*scale[c] + shift[c]) ("BN-on-read") before the bf16 hi/lo split.
+template <bool F16>
+__device__ __forceinline__ void stage_image_ptr(const float* __restrict__ src, int Cpitch, int c0, int cvalid4,
+                                            const int* sG, int npix, int C8, unsigned magic, char* img, int pitch,
+                                            int lo_off, bool prologue, const float* sScale, const float* sShift,
+                                            float pslope, int t) {
+  const int total = npix * C8;
+  for (int base = 0; base < total; base += 256 * 4) {
+    float4 va[4], vb[4];
+    int pix[4], c8s[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int item = base + u * 256 + t;
+      va[u] = make_float4(0.f, 0.f, 0.f, 0.f); vb[u] = va[u];
+      pix[u] = -1; c8s[u] = 0;
+      if (item < total) {
+        const int pixel = magic ? (int)__umulhi((unsigned)item, magic) : item;
+        const int c8 = item - pixel * C8;
+        pix[u] = pixel | 0x20000000; c8s[u] = c8;        // 0x2..: nothing loaded (stays zero, no prologue)
+        const int gp = sG[pixel];
+        if (gp >= 0 && c8 * 2 < cvalid4) {
+          const float* s = src + (size_t)gp * Cpitch + c0 + c8 * 8;
+          va[u] = *(const float4*)s;
+          pix[u] = pixel;
+          if (c8 * 2 + 1 < cvalid4) vb[u] = *(const float4*)(s + 4);
+          else pix[u] |= 0x40000000;                       // upper half of the chunk is channel padding
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (pix[u] == -1) continue;
+      const int pixel = pix[u] & 0x0fffffff;
+      const bool inside = !(pix[u] & 0x20000000);
+      const bool half = (pix[u] & 0x40000000) != 0;
+      float v[8] = {va[u].x, va[u].y, va[u].z, va[u].w, vb[u].x, vb[u].y, vb[u].z, vb[u].w};
+      if (prologue && inside) {
+        const float* sc = sScale + c0 + c8s[u] * 8; const float* sh = sShift + c0 + c8s[u] * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = md_leaky(fmaf(v[e], sc[e], sh[e]), pslope);
+        if (half) { v[4] = v[5] = v[6] = v[7] = 0.f; }
+      }
+      uint4 hi, lo;
+      if (F16) split8_f16(v, hi, lo); else split8(v, hi, lo);
+      char* d = img + pixel * pitch + c8s[u] * 16;
+      *(uint4*)d = hi;
+      *(uint4*)(d + lo_off) = lo;
+    }
+  }
+}
+
 
 // ================================================================================================
 // Weight gradient of a unit-stride convolution, split-bf16 arithmetic, LDS-resident operands.
@@ -1084,9 +914,9 @@ __global__ __launch_bounds__(256) void k_wgrad_patch(
       sGY[t] = ri.y;
     }
     __syncthreads();
-    if (!(dbg & 1)) stage_image<false>(src, g.Cpi, 0, g.Cpi >> 2, sG, g.P, g.C8i, g.magicC8, sP, g.ppitch, g.lo_off, prologue, sScale, sShift,
+    if (!(dbg & 1)) stage_image_ptr<false>(src, g.Cpi, 0, g.Cpi >> 2, sG, g.P, g.C8i, g.magicC8, sP, g.ppitch, g.lo_off, prologue, sScale, sShift,
                 pslope, t);
-    if (!(dbg & 2)) stage_image<false>(dy, g.Cpo, n0, ycv4, sGY, PM, g.NC, g.magicNC, sY, g.ypitch, g.ylo_off, false, nullptr, nullptr, 1.f, t);
+    if (!(dbg & 2)) stage_image_ptr<false>(dy, g.Cpo, n0, ycv4, sGY, PM, g.NC, g.magicNC, sY, g.ypitch, g.ylo_off, false, nullptr, nullptr, 1.f, t);
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < ((dbg & 4) ? 0 : 4); ++s) {

@@ -49,7 +49,9 @@ struct PGeom {
   int N16;
   unsigned magicC8;         // floor(2^32 / C8) + 1 : exact item / C8 for item < 2^16 (0 when the divisor is 1)
   unsigned m_pyx, m_px, m_byx, m_bx, m_khw, m_kw;   // same for the table decodes (all indices < 2^16)
-  unsigned src_bytes, dst_bytes;                      // tensor sizes for the buffer descriptors (< 4 GiB)
+  unsigned src_bytes, dst_bytes;                      // tensor sizes for the buffer descriptors (< 2 GiB)
+  int Tdf, Hdf, Wdf;        // full destination dims; destination coordinate = box coordinate * dm + dp
+  int dmt, dmh, dmw, dpt, dph, dpw;   // (one residue class of a strided data gradient writes a strided subset)
   int off_b, off_koffs, off_rows, off_pixg, off_scale;   // LDS byte offsets
   int pack2, pk_shift, pk_kw; // pixel-pair reinterpretation of a <=4-channel, W-stride-2 input (see patch_build)
 };
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(256) void k_conv_patch(
     const bool v = (rt < g.bt) && (t0 + rt < g.Td) && (y0 + ry < g.Hd) && (x0 + rx < g.Wd);
     int4 ri;
     ri.x = v ? ((rt * g.st * g.py + ry * g.sh) * g.px + rx * g.sw) * g.ppitch : 0;
-    ri.y = v ? ((n * g.Td + t0 + rt) * g.Hd + y0 + ry) * g.Wd + x0 + rx : -1;
+    ri.y = v ? ((n * g.Tdf + (t0 + rt) * g.dmt + g.dpt) * g.Hdf + (y0 + ry) * g.dmh + g.dph) * g.Wdf + (x0 + rx) * g.dmw + g.dpw : -1;
     ri.z = v ? ((base_t + rt) | ((base_h + ry) << 8) | ((base_w + rx) << 16)) : -1;
     ri.w = 0;
     sR[t] = ri;
@@ -435,38 +437,6 @@ __device__ __forceinline__ float pack2_weight(const float* __restrict__ w, int n
   return 0.f;
 }
 
-__global__ void k_pack_weights_x3(const float* __restrict__ w, int Cout, int Cin, int taps, int mode, int C8, int nstages,
-                                  int N16, unsigned short* __restrict__ out, int f16, int kwp = 0, int kw_real = 0,
-                                  int shift = 0, int taps_real = 0) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;     // over [stage][n][64]
-  const int total = nstages * N16 * 64;
-  if (idx >= total) return;
-  const int e64 = idx & 63; const int r = idx >> 6;
-  const int n = r % N16; const int kb = r / N16;
-  const int q = kb * 8 + (e64 >> 3);
-  const int tap = q / C8; const int ch = (q - tap * C8) * 8 + (e64 & 7);
-  float v = 0.f;
-  if (tap < taps) {
-    if (mode == 0) { if (n < Cout && ch < Cin) v = w[((size_t)n * Cin + ch) * taps + tap]; }
-    else if (mode == 1) { if (n < Cin && ch < Cout) v = w[((size_t)ch * Cin + n) * taps + (taps - 1 - tap)]; }
-    else if (mode == 2) { if (n < Cin && ch < Cout) v = w[((size_t)ch * Cin + n) * taps + tap]; }
-    else v = pack2_weight(w, n, tap, ch, Cout, Cin, kwp, kw_real, shift, taps_real);
-  }
-  const size_t o_hi = ((size_t)(kb * 2 + 0) * N16 + n) * 64 + e64;
-  const size_t o_lo = ((size_t)(kb * 2 + 1) * N16 + n) * 64 + e64;
-  if (f16) {
-    const _Float16 hi = (_Float16)v;
-    const _Float16 lo = (_Float16)(v - (float)hi);
-    out[o_hi] = __builtin_bit_cast(unsigned short, hi);
-    out[o_lo] = __builtin_bit_cast(unsigned short, lo);
-  } else {
-    const __bf16 hi = (__bf16)v;
-    const __bf16 lo = (__bf16)(v - (float)hi);
-    out[o_hi] = __builtin_bit_cast(unsigned short, hi);
-    out[o_lo] = __builtin_bit_cast(unsigned short, lo);
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -510,9 +480,13 @@ static bool choose_box(int T, int H, int W, int kt, int kh, int kw, int st, int 
 static unsigned magic_of(int d) { return d <= 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)d) + 1u; }
 static int ilog2_exact(int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; }
 
-static bool patch_build(const MdConvDesc* d, int dgrad, PGeom* out, size_t* lds_bytes) {
+// Residue class of a strided data gradient (see patch_classes): destination pixels i = s*j + c per dimension receive
+// only the taps tap0, tap0 + s, ... (kc of them); over the class grid j this is a unit-stride correlation.
+struct ClassSpec { int c[3], tap0[3], kc[3], e[3]; };
+
+static bool patch_build(const MdConvDesc* d, int dgrad, PGeom* out, size_t* lds_bytes, const ClassSpec* cls = nullptr) {
   PGeom g;
-  const bool sdg = dgrad && (d->st != 1 || d->sh != 1 || d->sw != 1);      // strided data gradient
+  const bool sdg = !cls && dgrad && (d->st != 1 || d->sh != 1 || d->sw != 1);      // strided data gradient, tap-test form
   g.strided = sdg ? 1 : 0;
   if (sdg && (ilog2_exact(d->st) < 0 || ilog2_exact(d->sh) < 0 || ilog2_exact(d->sw) < 0)) return false;
   g.st = dgrad ? 1 : d->st; g.sh = dgrad ? 1 : d->sh; g.sw = dgrad ? 1 : d->sw;
@@ -526,13 +500,27 @@ static bool patch_build(const MdConvDesc* d, int dgrad, PGeom* out, size_t* lds_
   g.kh = d->kh; g.kw = d->kw; g.khw = d->kh * d->kw; g.taps = d->kt * g.khw;
   if (!dgrad) { g.org_t = -d->pt; g.org_h = -d->ph; g.org_w = -d->pw; }
   else { g.org_t = d->pt - (d->kt - 1); g.org_h = d->ph - (d->kh - 1); g.org_w = d->pw - (d->kw - 1); }
+  g.Tdf = g.Td; g.Hdf = g.Hd; g.Wdf = g.Wd; g.dmt = g.dmh = g.dmw = 1; g.dpt = g.dph = g.dpw = 0;
+  int kt_eff = d->kt, kh_eff = d->kh;
+  if (cls) {
+    const int sd[3] = {d->st, d->sh, d->sw};
+    int cd_[3];
+    const int full[3] = {g.Td, g.Hd, g.Wd};
+    for (int i = 0; i < 3; ++i) cd_[i] = full[i] > cls->c[i] ? (full[i] - cls->c[i] + sd[i] - 1) / sd[i] : 0;
+    if (cd_[0] < 1 || cd_[1] < 1 || cd_[2] < 1) return false;
+    g.Td = cd_[0]; g.Hd = cd_[1]; g.Wd = cd_[2];
+    g.dmt = sd[0]; g.dmh = sd[1]; g.dmw = sd[2]; g.dpt = cls->c[0]; g.dph = cls->c[1]; g.dpw = cls->c[2];
+    g.kt = cls->kc[0]; g.kh = cls->kc[1]; g.kw = cls->kc[2]; g.khw = g.kh * g.kw; g.taps = g.kt * g.khw;
+    g.org_t = cls->e[0] - (cls->kc[0] - 1); g.org_h = cls->e[1] - (cls->kc[1] - 1); g.org_w = cls->e[2] - (cls->kc[2] - 1);
+    kt_eff = g.kt; kh_eff = g.kh;
+  }
   // Pixel-pair reinterpretation (forward): a <= 4-channel input read with W-stride 2 (the stem) would fill only half
   // of every 8-channel K chunk.  The same memory is a [.., Wi/2][8] tensor of pixel pairs, over which the convolution
   // has unit W-stride and kwp = ceil-ish(kw/2)+1 super-taps: output x reads pairs x + lo .. x + hi, and super-tap sx',
   // channel 4j+c carries real tap dx = 2 sx' + j + shift (zero weight where dx falls outside the filter).
   g.pack2 = 0; g.pk_shift = 0; g.pk_kw = d->kw;
   static const int no_pack2 = getenv("MD_PACK2") && atoi(getenv("MD_PACK2")) == 0;
-  int kw_eff = d->kw, sw_eff = g.sw;
+  int kw_eff = cls ? g.kw : d->kw, sw_eff = g.sw;
   if (!dgrad && !no_pack2 && g.Cps == 4 && d->sw == 2 && (d->Wi & 1) == 0 && d->kw >= 2) {
     const int lo = -((d->pw + 1) / 2);
     const int num = d->kw - 1 - d->pw;
@@ -550,7 +538,7 @@ static bool patch_build(const MdConvDesc* d, int dgrad, PGeom* out, size_t* lds_
   g.magicC8 = magic_of(g.C8);
   {
     const unsigned long long sb = (unsigned long long)d->N * g.Ts * g.Hs * g.Ws * g.Cps * 4ull;
-    const unsigned long long db = (unsigned long long)d->N * g.Td * g.Hd * g.Wd * g.Cpd * 4ull;
+    const unsigned long long db = (unsigned long long)d->N * g.Tdf * g.Hdf * g.Wdf * g.Cpd * 4ull;
     if (sb >= 0x80000000ull || db >= 0x80000000ull) return false;     // buffer addressing: 2 GiB per tensor
     g.src_bytes = (unsigned)sb; g.dst_bytes = (unsigned)db;
   }
@@ -569,12 +557,12 @@ static bool patch_build(const MdConvDesc* d, int dgrad, PGeom* out, size_t* lds_
   if (maxP > idx_cap) maxP = idx_cap;
   if (softP < 1) softP = 1;
   if (maxP < 1) return false;
-  if (!choose_box(g.Td, g.Hd, g.Wd, d->kt, d->kh, kw_eff, sdg ? d->st : g.st, sdg ? d->sh : g.sh, sdg ? d->sw : sw_eff, sdg,
+  if (!choose_box(g.Td, g.Hd, g.Wd, kt_eff, kh_eff, kw_eff, sdg ? d->st : g.st, sdg ? d->sh : g.sh, sdg ? d->sw : sw_eff, sdg,
                   (int)maxP, (int)softP, &g.bt, &g.by, &g.bx)) return false;
   g.byx = g.by * g.bx;
   g.nbt = md_cdiv(g.Td, g.bt); g.nby = md_cdiv(g.Hd, g.by); g.nbx = md_cdiv(g.Wd, g.bx);
   if (!sdg) {
-    g.pt = (g.bt - 1) * g.st + d->kt; g.py = (g.by - 1) * g.sh + d->kh; g.px = (g.bx - 1) * g.sw + g.kw;
+    g.pt = (g.bt - 1) * g.st + kt_eff; g.py = (g.by - 1) * g.sh + kh_eff; g.px = (g.bx - 1) * g.sw + g.kw;
   } else {
     g.pt = (g.bt + d->kt - 2) / d->st + 2; g.py = (g.by + d->kh - 2) / d->sh + 2; g.px = (g.bx + d->kw - 2) / d->sw + 2;
   }
@@ -596,7 +584,43 @@ static bool patch_build(const MdConvDesc* d, int dgrad, PGeom* out, size_t* lds_
   return true;
 }
 
-struct PatchPlan { PGeom g; size_t lds; int N; int dgrad; };
+struct PatchClass { PGeom g; size_t lds; size_t wp_off; ClassSpec spec; };     // wp_off: floats into the packed operand
+struct PatchPlan { PGeom g; size_t lds; int N; int dgrad; int ncls; PatchClass cls[8]; };
+
+// Strided data gradient by residue classes.  dX[i] = sum over taps with (i + pad - tap) % s == 0 of
+// dY[(i + pad - tap) / s] W[tap].  For i = s*j + c the valid taps are tap0 + s*a, tap0 = (c + pad) % s, a < kc, and the
+// source is j + e - a with e = (c + pad - tap0) / s: one dense unit-stride problem per class (s_t*s_h*s_w of them)
+// instead of testing every tap for every pixel.  Needs k >= s in every strided dimension (each class has a tap).
+static int patch_classes(const MdConvDesc* d, PatchPlan* pp) {
+  const int sd[3] = {d->st, d->sh, d->sw}, kd[3] = {d->kt, d->kh, d->kw}, pd[3] = {d->pt, d->ph, d->pw};
+  const int full[3] = {d->Ti, d->Hi, d->Wi};
+  for (int i = 0; i < 3; ++i) if (sd[i] > 1 && kd[i] < sd[i]) return 0;
+  if (sd[0] * sd[1] * sd[2] > 8) return 0;
+  // one launch per class: worth it only when each still fills the chip (measured: 704 boxes gain, 176 boxes lose)
+  static const long long min_px = getenv("MD_DGRAD_CLASS_MIN_PX") ? atoll(getenv("MD_DGRAD_CLASS_MIN_PX")) : 65536;
+  if ((long long)d->N * d->Ti * d->Hi * d->Wi < min_px) return 0;
+  int n = 0; size_t off = 0;
+  for (int ct = 0; ct < sd[0]; ++ct)
+    for (int ch = 0; ch < sd[1]; ++ch)
+      for (int cw = 0; cw < sd[2]; ++cw) {
+        ClassSpec cs; const int c[3] = {ct, ch, cw};
+        bool empty = false;
+        for (int i = 0; i < 3; ++i) {
+          cs.c[i] = c[i]; cs.tap0[i] = (c[i] + pd[i]) % sd[i];
+          cs.kc[i] = (kd[i] - cs.tap0[i] + sd[i] - 1) / sd[i];
+          cs.e[i] = (c[i] + pd[i] - cs.tap0[i]) / sd[i];
+          if (c[i] >= full[i]) empty = true;
+          if (cs.kc[i] < 1) return 0;
+        }
+        if (empty) continue;                 // no destination pixel in this class
+        PatchClass& pc = pp->cls[n];
+        if (!patch_build(d, 1, &pc.g, &pc.lds, &cs)) return 0;
+        pc.spec = cs; pc.wp_off = off;
+        off += (size_t)pc.g.nstages * 2 * pc.g.N16 * 64 / 2;
+        ++n;
+      }
+  return n;
+}
 
 #include <map>
 #include <mutex>
@@ -623,14 +647,27 @@ const PatchPlan* patch_lookup(const MdConvDesc* d, int dgrad) {
   if (it != cache.end()) return it->second;
   PatchPlan* pp = nullptr;
   PGeom g; size_t lds = 0;
-  if (patch_build(d, dgrad, &g, &lds)) { pp = new PatchPlan(); pp->g = g; pp->lds = lds; pp->N = d->N; pp->dgrad = dgrad; }
+  static const int no_cls = getenv("MD_DGRAD_CLASSES") && atoi(getenv("MD_DGRAD_CLASSES")) == 0;
+  if (dgrad && !no_cls && (d->st != 1 || d->sh != 1 || d->sw != 1)) {
+    PatchPlan* cp = new PatchPlan();
+    cp->ncls = patch_classes(d, cp);
+    if (cp->ncls > 0) { cp->g = cp->cls[0].g; cp->lds = cp->cls[0].lds; cp->N = d->N; cp->dgrad = 1; pp = cp; }
+    else delete cp;
+  }
+  if (!pp && patch_build(d, dgrad, &g, &lds)) {
+    pp = new PatchPlan(); pp->g = g; pp->lds = lds; pp->N = d->N; pp->dgrad = dgrad; pp->ncls = 0;
+  }
   cache[key] = pp;
   return pp;
 }
 
 // ---- batched weight packing: one launch for every patch-format operand of a network (<= 64 items by value)
 #define PACK_BATCH 64
-struct PackItem { const float* w; unsigned short* out; int Cout, Cin, taps, mode, C8, nstages, N16, f16, total, kwp, kw_real, shift, taps_real; };
+struct PackItem {
+  const float* w; unsigned short* out;
+  int Cout, Cin, taps, mode, C8, nstages, N16, f16, total, kwp, kw_real, shift, taps_real;
+  int kc[3], tap0[3], cs[3], kh_real;       // mode 4: residue class of a strided data gradient
+};
 struct PackBatch { PackItem it[PACK_BATCH]; };
 __global__ __launch_bounds__(256) void k_pack_weights_batch(PackBatch pb) {
   const PackItem& q = pb.it[blockIdx.y];
@@ -645,7 +682,14 @@ __global__ __launch_bounds__(256) void k_pack_weights_batch(PackBatch pb) {
     if (q.mode == 0) { if (n < q.Cout && ch < q.Cin) v = q.w[((size_t)n * q.Cin + ch) * q.taps + tap]; }
     else if (q.mode == 1) { if (n < q.Cin && ch < q.Cout) v = q.w[((size_t)ch * q.Cin + n) * q.taps + (q.taps - 1 - tap)]; }
     else if (q.mode == 2) { if (n < q.Cin && ch < q.Cout) v = q.w[((size_t)ch * q.Cin + n) * q.taps + tap]; }
-    else v = pack2_weight(q.w, n, tap, ch, q.Cout, q.Cin, q.kwp, q.kw_real, q.shift, q.taps_real);
+    else if (q.mode == 3) v = pack2_weight(q.w, n, tap, ch, q.Cout, q.Cin, q.kwp, q.kw_real, q.shift, q.taps_real);
+    else {      // mode 4: sub-tap (a't, a'h, a'w) of the class <-> real tap tap0 + s * (kc - 1 - a') per dimension
+      const int khw = q.kc[1] * q.kc[2];
+      const int at = tap / khw, r2 = tap - at * khw, ah = r2 / q.kc[2], aw = r2 - ah * q.kc[2];
+      const int rt = q.tap0[0] + q.cs[0] * (q.kc[0] - 1 - at), rh = q.tap0[1] + q.cs[1] * (q.kc[1] - 1 - ah),
+                rw = q.tap0[2] + q.cs[2] * (q.kc[2] - 1 - aw);
+      if (n < q.Cin && ch < q.Cout) v = q.w[((size_t)ch * q.Cin + n) * q.taps_real + (rt * q.kh_real + rh) * q.kw_real + rw];
+    }
   }
   const size_t o_hi = ((size_t)(kb * 2 + 0) * q.N16 + n) * 64 + e64;
   const size_t o_lo = ((size_t)(kb * 2 + 1) * q.N16 + n) * 64 + e64;
@@ -675,39 +719,48 @@ int patch_pack_batch(int n, const MdConvDesc* const* descs, const int* dgrad, co
     if (!outs[i]) { handled[i] = 1; continue; }
     const PatchPlan* pp = patch_lookup(descs[i], dgrad[i]);
     if (!pp) continue;
-    const PGeom& g = pp->g;
-    PackItem& q = pb.it[cnt++];
-    q.w = w[i]; q.out = (unsigned short*)outs[i]; q.Cout = descs[i]->Cout; q.Cin = descs[i]->Cin; q.taps = g.taps;
-    q.mode = dgrad[i] ? (g.strided ? 2 : 1) : (g.pack2 ? 3 : 0); q.C8 = g.C8; q.nstages = g.nstages; q.N16 = g.N16;
-    q.f16 = dgrad[i] ? 0 : 1;
-    q.kwp = g.kw; q.kw_real = g.pk_kw; q.shift = g.pk_shift; q.taps_real = descs[i]->kt * descs[i]->kh * descs[i]->kw;
-    q.total = g.nstages * g.N16 * 64;
-    if (q.total > maxtot) maxtot = q.total;
+    const int nit = pp->ncls ? pp->ncls : 1;
+    for (int c = 0; c < nit; ++c) {
+      const PGeom& g = pp->ncls ? pp->cls[c].g : pp->g;
+      PackItem& q = pb.it[cnt++];
+      q.w = w[i]; q.out = (unsigned short*)(outs[i] + (pp->ncls ? pp->cls[c].wp_off : 0));
+      q.Cout = descs[i]->Cout; q.Cin = descs[i]->Cin; q.taps = g.taps;
+      q.mode = pp->ncls ? 4 : dgrad[i] ? (g.strided ? 2 : 1) : (g.pack2 ? 3 : 0);
+      q.C8 = g.C8; q.nstages = g.nstages; q.N16 = g.N16; q.f16 = dgrad[i] ? 0 : 1;
+      q.kwp = g.kw; q.kw_real = pp->ncls ? descs[i]->kw : g.pk_kw; q.shift = g.pk_shift;
+      q.taps_real = descs[i]->kt * descs[i]->kh * descs[i]->kw; q.kh_real = descs[i]->kh;
+      const int sd[3] = {descs[i]->st, descs[i]->sh, descs[i]->sw};
+      for (int k = 0; k < 3; ++k) {
+        q.kc[k] = pp->ncls ? pp->cls[c].spec.kc[k] : 1; q.tap0[k] = pp->ncls ? pp->cls[c].spec.tap0[k] : 0; q.cs[k] = sd[k];
+      }
+      q.total = g.nstages * g.N16 * 64;
+      if (q.total > maxtot) maxtot = q.total;
+      if (cnt == PACK_BATCH) { int rc = flush(); if (rc) return rc; }
+    }
     handled[i] = 1;
-    if (cnt == PACK_BATCH) { int rc = flush(); if (rc) return rc; }
   }
   return flush();
 }
 
-size_t patch_wpack_floats(const PatchPlan* p) { return (size_t)p->g.nstages * 2 * p->g.N16 * 64 / 2; }   // bf16 count / 2
+size_t patch_wpack_floats(const PatchPlan* p) {      // 16-bit element count / 2
+  if (!p->ncls) return (size_t)p->g.nstages * 2 * p->g.N16 * 64 / 2;
+  const PatchClass& l = p->cls[p->ncls - 1];
+  return l.wp_off + (size_t)l.g.nstages * 2 * l.g.N16 * 64 / 2;
+}
 int patch_blocks(const PatchPlan* p) { return p->N * p->g.nbt * p->g.nby * p->g.nbx; }
 
 int patch_pack(const MdConvDesc* d, int dgrad, const PatchPlan* p, const float* w, float* out, hipStream_t s) {
-  const PGeom& g = p->g;
-  const int total = g.nstages * g.N16 * 64;
-  MD_KLAUNCH(k_pack_weights_x3, dim3(md_cdiv(total, 256)), dim3(256), 0, s, w, d->Cout, d->Cin, g.taps,
-             dgrad ? (g.strided ? 2 : 1) : (g.pack2 ? 3 : 0), g.C8, g.nstages, g.N16, (unsigned short*)out, dgrad ? 0 : 1, g.kw,
-             g.pk_kw, g.pk_shift, d->kt * d->kh * d->kw);
-  MD_CHECK_LAUNCH();
-  return MD_OK;
+  (void)p;
+  unsigned char handled = 0;
+  const int rc = patch_pack_batch(1, &d, &dgrad, &w, &out, &handled, s);
+  return rc ? rc : (handled ? MD_OK : MD_ERR_UNSUPPORTED);
 }
 
-int patch_launch(const PatchPlan* p, const float* src, const float* ps, const float* psh, float slope, const float* wp,
-                 float* dst, float* stat, int accumulate, hipStream_t s) {
-  const PGeom& g = p->g;
+static int patch_launch_one(const PatchPlan* p, const PGeom& g, size_t lds, const float* src, const float* ps, const float* psh,
+                            float slope, const float* wp, float* dst, float* stat, int accumulate, hipStream_t s) {
   const int nchunks = md_cdiv(g.N16, PNREP * 16);
   const int npb = md_round_up(md_cdiv(g.N16, nchunks), 16);
-  dim3 grid(patch_blocks(p), md_cdiv(g.N16, npb));
+  dim3 grid(p->N * g.nbt * g.nby * g.nbx, md_cdiv(g.N16, npb));
   static const int dbg = getenv("MD_DBG") ? atoi(getenv("MD_DBG")) : 0;
   accumulate = (accumulate & 1) | ((dbg & 0xff) << 8);
   const int nrep = npb / 16;
@@ -719,7 +772,7 @@ int patch_launch(const PatchPlan* p, const float* src, const float* ps, const fl
                               160 * 1024) != hipSuccess) return MD_ERR_LAUNCH;                                          \
       set_ = true;                                                                                                      \
     }                                                                                                                   \
-    MD_KLAUNCH((k_conv_patch<F16_, STR_, NR_>), grid, dim3(256), p->lds, s, g, src, ps, psh, slope,             \
+    MD_KLAUNCH((k_conv_patch<F16_, STR_, NR_>), grid, dim3(256), lds, s, g, src, ps, psh, slope,                \
                        (const uint4*)wp, dst, stat, accumulate, npb);                                                   \
   } while (0)
 #define LAUNCH_PATCH_NR(F16_, STR_)                                                                                     \
@@ -738,6 +791,17 @@ int patch_launch(const PatchPlan* p, const float* src, const float* ps, const fl
   else if (!g.strided) { LAUNCH_PATCH_NR(false, false); }
   else { LAUNCH_PATCH_NR(false, true); }
   MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+int patch_launch(const PatchPlan* p, const float* src, const float* ps, const float* psh, float slope, const float* wp,
+                 float* dst, float* stat, int accumulate, hipStream_t s) {
+  if (!p->ncls) return patch_launch_one(p, p->g, p->lds, src, ps, psh, slope, wp, dst, stat, accumulate, s);
+  for (int c = 0; c < p->ncls; ++c) {        // residue classes write disjoint pixels of dst
+    const int rc = patch_launch_one(p, p->cls[c].g, p->cls[c].lds, src, ps, psh, slope, wp + p->cls[c].wp_off, dst, stat,
+                                    accumulate, s);
+    if (rc) return rc;
+  }
   return MD_OK;
 }
 
@@ -1129,12 +1193,23 @@ __global__ __launch_bounds__(256) void k_wgrad_patch_pf(
 
   const int box_beg = blockIdx.x * g.boxes_per_wg;
   const int box_end = min(g.nboxes, box_beg + g.boxes_per_wg);
+#ifdef MD_PHASE_TIMING
+  long long tph[6] = {0, 0, 0, 0, 0, 0}, tc0 = clock64(), tc1;
+#define PH(i) do { tc1 = clock64(); tph[i] += tc1 - tc0; tc0 = tc1; } while (0)
+#else
+#define PH(i)
+#endif
   if (box_beg < box_end) issue(box_beg);
+  PH(0);
   for (int box = box_beg; box < box_end; ++box) {
     __syncthreads();          // previous box fully consumed (first iteration: tables / scale in LDS)
+    PH(1);
     commit();
+    PH(2);
     __syncthreads();
+    PH(3);
     if (box + 1 < box_end) issue(box + 1);      // in flight during the MFMA phase below
+    PH(4);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int r0 = s * 32 + lg * 4 + lq;
@@ -1158,7 +1233,12 @@ __global__ __launch_bounds__(256) void k_wgrad_patch_pf(
         }
       }
     }
+    PH(5);
   }
+#ifdef MD_PHASE_TIMING
+  if (blockIdx.x == 7 && blockIdx.y == 0 && (t == 0 || t == 192))
+    printf("wgrad_pf t=%d boxes=%d issue0=%lld bar1=%lld commit=%lld bar2=%lld issue=%lld mfma=%lld\n", t, box_end - box_beg, tph[0], tph[1], tph[2], tph[3], tph[4], tph[5]);
+#endif
 
   float* out = slab + (size_t)blockIdx.x * g.nkt * 16 * g.N16;
 #pragma unroll

@@ -56,6 +56,12 @@ CASES = [
     ("pair4p1w", 2, 7, (1, 3, 4), (1, 1, 2), (0, 1, 1), (2, 2, 7, 10)),
     ("pair2p2", 3, 5, (1, 1, 2), (1, 1, 2), (0, 0, 2), (1, 2, 5, 8)),
     ("pair7p0", 3, 45, (1, 7, 7), (1, 2, 2), (0, 3, 0), (1, 2, 20, 134)),
+    # strided data gradient by residue classes (used from 65536 destination pixels up): odd sizes, every stride pattern
+    ("cls_s122", 16, 24, (1, 3, 3), (1, 2, 2), (0, 1, 1), (2, 2, 131, 128)),
+    ("cls_s211", 24, 16, (3, 1, 1), (2, 1, 1), (1, 0, 0), (2, 9, 64, 64)),
+    ("cls_s222", 8, 12, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 9, 90, 93)),
+    ("cls_k2p0", 8, 8, (1, 2, 2), (1, 2, 2), (0, 0, 0), (1, 2, 182, 182)),
+    ("cls_k5p2", 4, 20, (1, 5, 4), (1, 2, 2), (0, 2, 1), (1, 3, 150, 151)),
 ]
 
 

@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--torch-optimizer", action="store_true", help="torch clip_grad_norm_ + fused AdamW instead of src.optim.ClipAdamW")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -114,10 +115,11 @@ def main():
         broadcast_module_state(model, 0)
         reducer = GradAllReducer(model)
     loss_fn = FocalLoss(weight=torch.ones(2), gamma=2.0)
-    try:
+    from src.optim import ClipAdamW
+    if args.torch_optimizer:
         opt = torch.optim.AdamW(model.parameters(), lr=2e-4, fused=True)
-    except Exception:
-        opt = torch.optim.AdamW(model.parameters(), lr=2e-4)
+    else:
+        opt = ClipAdamW(model.parameters(), lr=2e-4)      # same arithmetic as clip_grad_norm_ + AdamW, three launches
     x, y = synth_batch(device, 1234 + rank)
     finite = torch.ones((), device=device)
 
@@ -129,8 +131,11 @@ def main():
         loss.backward()
         if reducer is not None:
             reducer.reduce_rest()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
-        opt.step()
+        if args.torch_optimizer:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+            opt.step()
+        else:
+            opt.step(max_norm=1.0)
         finite = finite * torch.isfinite(loss.detach()).float()       # checked after the timed region, no host sync here
 
     for _ in range(args.warmup):

@@ -152,9 +152,12 @@ def dp_train_step(model, reducer: GradAllReducer, optimizer, loss_fn, data, targ
         return loss.detach(), output.detach(), False
     loss.backward()
     reducer.reduce_rest()
-    if max_norm_grad:
-        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm_grad)
-    optimizer.step()
+    if getattr(optimizer, "fused_clip", False):             # src.optim.ClipAdamW: clip + update in one pass
+        optimizer.step(max_norm=max_norm_grad)
+    else:
+        if max_norm_grad:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm_grad)
+        optimizer.step()
     return loss.detach(), output.detach(), True
 
 

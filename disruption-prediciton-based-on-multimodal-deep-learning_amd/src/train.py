@@ -95,9 +95,12 @@ def train_per_epoch(
             continue
         loss.backward()
 
-        if max_norm_grad:
-            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm_grad)
-        optimizer.step()
+        if getattr(optimizer, "fused_clip", False):         # src.optim.ClipAdamW: clip + update in one pass
+            optimizer.step(max_norm=max_norm_grad)
+        else:
+            if max_norm_grad:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm_grad)
+            optimizer.step()
 
         ld = loss.detach()
         loss_sum = ld if loss_sum is None else loss_sum + ld

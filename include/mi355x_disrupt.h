@@ -170,6 +170,24 @@ int md_softmax_loss(int32_t kind, const float* logits, const int64_t* target, in
                     float* loss, float* dlogits, int64_t* pred, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Optimizer step: torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm) + torch.optim.AdamW.step()
+ * (src/train.py:64-66, train_vision_network.py:277-278) over all parameter tensors in two launches.
+ * `tensors` is a device array of MdOptTensor, `chunks` a device array of MdOptChunk covering every tensor in pieces
+ * of md_opt_chunk_elems() elements (the last piece of a tensor may be short).  All pointers fp32, 4-byte aligned.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct MdOptTensor { float* param; float* grad; float* exp_avg; float* exp_avg_sq; int64_t numel; } MdOptTensor;
+typedef struct MdOptChunk { int32_t tensor; int32_t offset; } MdOptChunk;   /* offset in chunks from the tensor's start */
+int md_opt_chunk_elems(void);
+/* norm_coef[0] = 2-norm over all gradients, norm_coef[1] = min(1, max_norm / (norm + 1e-6)) (1 if max_norm <= 0);
+ * partial: nchunks floats of scratch.  Deterministic (fixed summation order). */
+int md_opt_grad_norm(const void* tensors, const void* chunks, int32_t nchunks, float max_norm, float* partial,
+                     float* norm_coef, void* stream);
+/* One AdamW step (decoupled weight decay, bias correction for `step` >= 1, no amsgrad).  If norm_coef != NULL the
+ * gradients are first scaled by norm_coef[1] in place, as clip_grad_norm_ does. */
+int md_opt_adamw_step(const void* tensors, const void* chunks, int32_t nchunks, const float* norm_coef, float lr,
+                      float beta1, float beta2, float eps, float weight_decay, int64_t step, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Whole-trunk executor: R2Plus1DNet.forward / backward (R2Plus1D.py:207-226) as one plan.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct MdPlan MdPlan;

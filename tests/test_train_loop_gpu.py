@@ -36,8 +36,9 @@ def _model(ls, T, S, alpha, seed):
     return m.to(DEV)
 
 
+@pytest.mark.parametrize("fused_opt", [False, True], ids=["torch_adamw", "clip_adamw"])
 @pytest.mark.parametrize("exact", [True, False], ids=["exact_fp32", "split"])
-def test_train_per_epoch_matches_reference_step_fixture(golden_dir, exact):
+def test_train_per_epoch_matches_reference_step_fixture(golden_dir, exact, fused_opt):
     g = np.load(os.path.join(golden_dir, "step_tiny.npz"))
     ls = [int(v) for v in g["layer_sizes"]]
     B, T, S, alpha, seed = int(g["B"]), int(g["T"]), int(g["S"]), float(g["alpha"]), int(g["seed"])
@@ -46,7 +47,11 @@ def test_train_per_epoch_matches_reference_step_fixture(golden_dir, exact):
         model = _model(ls, T, S, alpha, seed)
         before = {k: v.detach().clone() for k, v in model.named_parameters()}
         batches = [(orc.synth_clip(B, T, S, seed + i), orc.synth_labels(B, seed + i, 0.4)) for i in range(3)]
-        opt = torch.optim.AdamW(model.parameters(), lr=2e-4)
+        if fused_opt:      # src.optim.ClipAdamW: clip_grad_norm_ + AdamW through md_opt_* (same fixture, same bars)
+            from src.optim import ClipAdamW
+            opt = ClipAdamW(model.parameters(), lr=2e-4)
+        else:
+            opt = torch.optim.AdamW(model.parameters(), lr=2e-4)
         loss_fn = FocalLoss(weight=torch.tensor([1.0, 1.0]), gamma=2.0)
         preds = []
         hook = model.register_forward_hook(lambda m, i, o: preds.append(torch.softmax(o, 1).max(1)[1].cpu().numpy().copy()))

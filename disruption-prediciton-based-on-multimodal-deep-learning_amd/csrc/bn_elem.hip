@@ -37,14 +37,17 @@ __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(
 
 // Row walk shared by the streaming kernels: thread -> (chunk c4, row lane r); block -> row range.
 struct RowWalk { int c4, r, nr; int64_t beg, end; bool active; };
-__device__ __forceinline__ RowWalk row_walk(int64_t rows, int C4) {
+// `bid`: which contiguous slice of rows this block walks (blockIdx.x, or the mirrored index for a pass that should
+// start where the previous kernel finished writing, while those lines are still in L2 / Infinity Cache).
+__device__ __forceinline__ RowWalk row_walk(int64_t rows, int C4, int bid = -1) {
   RowWalk w;
+  if (bid < 0) bid = blockIdx.x;
   w.nr = blockDim.x / C4;
   w.c4 = threadIdx.x % C4;
   w.r = threadIdx.x / C4;
   w.active = w.r < w.nr;
   const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
-  w.beg = (int64_t)blockIdx.x * per;
+  w.beg = (int64_t)bid * per;
   w.end = w.beg + per < rows ? w.beg + per : rows;
   return w;
 }
@@ -160,7 +163,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd(const float* __restrict__ dA, Vi
                                                 int64_t rows, int C4, float* __restrict__ partial,
                                                 float* __restrict__ d_raw, float* __restrict__ dS) {
   __shared__ float4 red[256];
-  RowWalk w = row_walk(rows, C4);
+  // The reduction pass walks the tensor back to front: dA was just written front to back by the data-gradient kernel,
+  // and the apply pass that follows (front to back) then starts on what this pass touched last.
+  const int bid = APPLY ? (int)blockIdx.x : (int)(gridDim.x - 1 - blockIdx.x);
+  RowWalk w = row_walk(rows, C4, bid);
   const int Cp = C4 * 4;
   float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1;
   if (w.active) {
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd(const float* __restrict__ dA, Vi
   }
   if (!APPLY) {
     // reduce over the row lanes of this block (fixed order), one partial row per block
-    float* sp = partial + (size_t)blockIdx.x * 2 * Cp;
+    float* sp = partial + (size_t)bid * 2 * Cp;
     red[threadIdx.x] = a1;
     __syncthreads();
     if (w.r == 0 && w.active) {

@@ -1372,6 +1372,37 @@ static bool wgrad_build(const MdConvDesc* d, WGeom* out, size_t* lds_bytes, int*
   return true;
 }
 
+static bool wgrad_use_pf(const WGeom& g) {
+  static const int no_pf = getenv("MD_WGRAD_PF") && atoi(getenv("MD_WGRAD_PF")) == 0;
+  static const int dbg = getenv("MD_DBG") ? atoi(getenv("MD_DBG")) : 0;
+  return !no_pf && !dbg && g.P * g.C8i <= WPF_X * 256 && PM * g.NC <= WPF_Y * 256 && g.pt < 64 && g.py < 512 && g.px < 512 &&
+         g.bt < 64;
+}
+template <int KT, int NR>
+static const void* wgrad_kernel_of(bool pf) { return pf ? (const void*)k_wgrad_patch_pf<KT, NR> : (const void*)k_wgrad_patch<KT, NR>; }
+template <int KT>
+static const void* wgrad_kernel_nr(int nrep, bool pf) {
+  switch (nrep) {
+    case 1: return wgrad_kernel_of<KT, 1>(pf);
+    case 2: return wgrad_kernel_of<KT, 2>(pf);
+    case 3: return wgrad_kernel_of<KT, 3>(pf);
+    case 4: return wgrad_kernel_of<KT, 4>(pf);
+    default: return wgrad_kernel_of<KT, 5>(pf);
+  }
+}
+// Workgroups of this kernel that fit on one CU (registers and LDS); 2 when the runtime cannot say (no device).
+static int wgrad_wgs_per_cu(const WGeom& g, size_t lds) {
+  const bool pf = wgrad_use_pf(g);
+  const void* k = g.ktw == 3 ? wgrad_kernel_nr<3>(g.nrep, pf) : g.ktw == 4 ? wgrad_kernel_nr<4>(g.nrep, pf) : wgrad_kernel_nr<5>(g.nrep, pf);
+  int nb = 0;
+  if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 256, lds) != hipSuccess || nb < 1) {
+    (void)hipGetLastError();
+    return 2;
+  }
+  return nb > 2 ? 2 : nb;
+}
+
 const WgradPlan* wgrad_lookup(const MdConvDesc* d) {
   if (g_exact_fp32.load()) return nullptr;
   static const int dis = getenv("MD_PATCH_WGRAD") && atoi(getenv("MD_PATCH_WGRAD")) == 0;
@@ -1385,7 +1416,16 @@ const WgradPlan* wgrad_lookup(const MdConvDesc* d) {
   if (it != cache.end()) return it->second;
   WgradPlan* wp = nullptr;
   WGeom g; size_t lds = 0; int ns = 0;
-  if (wgrad_build(d, &g, &lds, &ns)) { wp = new WgradPlan(); wp->g = g; wp->lds = lds; wp->nslices = ns; }
+  if (wgrad_build(d, &g, &lds, &ns)) {
+    // one slice (= one slab of partial sums) per resident workgroup: a single full round on the chip, and no more
+    // slab traffic than that needs
+    int want = md_cdiv(256 * wgrad_wgs_per_cu(g, lds), g.nkg * g.nng);
+    if (want > g.nboxes) want = g.nboxes;
+    if (want < 1) want = 1;
+    g.boxes_per_wg = md_cdiv(g.nboxes, want);
+    ns = md_cdiv(g.nboxes, g.boxes_per_wg);
+    wp = new WgradPlan(); wp->g = g; wp->lds = lds; wp->nslices = ns;
+  }
   cache[key] = wp;
   return wp;
 }
@@ -1397,9 +1437,7 @@ int wgrad_patch_launch(const WgradPlan* p, const MdConvDesc* d, const float* src
   const WGeom& g = p->g;
   static const int dbg = getenv("MD_DBG") ? atoi(getenv("MD_DBG")) : 0;
   dim3 grid(p->nslices, g.nkg * g.nng);
-  static const int no_pf = getenv("MD_WGRAD_PF") && atoi(getenv("MD_WGRAD_PF")) == 0;
-  const bool pf = !no_pf && !dbg && g.P * g.C8i <= WPF_X * 256 && PM * g.NC <= WPF_Y * 256 && g.pt < 64 && g.py < 512 &&
-                  g.px < 512 && g.bt < 64;
+  const bool pf = wgrad_use_pf(g);
 #define LAUNCH_WG(KT_, NR_)                                                                                             \
   do {                                                                                                                  \
     static bool set_ = false;                                                                                           \

@@ -758,9 +758,16 @@ int patch_pack(const MdConvDesc* d, int dgrad, const PatchPlan* p, const float* 
 
 static int patch_launch_one(const PatchPlan* p, const PGeom& g, size_t lds, const float* src, const float* ps, const float* psh,
                             float slope, const float* wp, float* dst, float* stat, int accumulate, hipStream_t s) {
-  const int nchunks = md_cdiv(g.N16, PNREP * 16);
+  int nchunks = md_cdiv(g.N16, PNREP * 16);
+  const int boxes = p->N * g.nbt * g.nby * g.nbx;
+  {   // few boxes (the deep, small layers): split the destination channels over more workgroups so every CU gets one
+    static const int fill = getenv("MD_PATCH_FILL") ? atoi(getenv("MD_PATCH_FILL")) : 128;     // measured: 64 / 128 / 256 / 512
+    int wantc = md_cdiv(fill, boxes);
+    if (wantc > g.N16 / 16) wantc = g.N16 / 16;
+    if (wantc > nchunks) nchunks = wantc;
+  }
   const int npb = md_round_up(md_cdiv(g.N16, nchunks), 16);
-  dim3 grid(p->N * g.nbt * g.nby * g.nbx, md_cdiv(g.N16, npb));
+  dim3 grid(boxes, md_cdiv(g.N16, npb));
   static const int dbg = getenv("MD_DBG") ? atoi(getenv("MD_DBG")) : 0;
   accumulate = (accumulate & 1) | ((dbg & 0xff) << 8);
   const int nrep = npb / 16;

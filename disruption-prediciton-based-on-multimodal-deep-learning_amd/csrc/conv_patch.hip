@@ -580,6 +580,10 @@ static bool patch_build(const MdConvDesc* d, int dgrad, PGeom* out, size_t* lds_
   g.off_pixg = (int)off; off += (size_t)((g.P * 4 + 15) & ~15);
   g.off_scale = (int)off; off += (size_t)2 * PMAXC * 4;
   if (off > cap) return false;
+  if (getenv("MD_PLAN_PRINT"))
+    fprintf(stderr, "patch %s %d->%d k%d%d%d s%d%d%d dst %dx%dx%d: box %dx%dx%d patch %dx%dx%d=%d C8=%d stages=%d lds=%zu\n",
+            dgrad ? (cls ? "dgrad-class" : "dgrad") : "fwd", d->Cin, d->Cout, d->kt, d->kh, d->kw, d->st, d->sh, d->sw, g.Td, g.Hd,
+            g.Wd, g.bt, g.by, g.bx, g.pt, g.py, g.px, g.P, g.C8, g.nstages, off);
   *out = g; *lds_bytes = off;
   return true;
 }
@@ -903,6 +907,7 @@ struct WGeom {
   int off_y, off_rows, off_pixg, off_scale;
   int pack2, pk_shift, pk_kw;   // pixel-pair reinterpretation (see wgrad_build); then kw = k-tiles per filter row
   int tapw;                     // X patch bytes between successive values of the kw index
+  unsigned x_bytes, y_bytes;    // tensor sizes for the buffer descriptors (< 2 GiB)
 };
 
 __device__ __forceinline__ bf16x8 tr_read2(const char* p0, const char* p1) {
@@ -1098,10 +1103,11 @@ __global__ __launch_bounds__(256) void k_wgrad_patch_pf(
   const int ycv4 = max(0, min(g.NC * 2, (g.Cpo - n0) >> 2));
   int xloc[WPF_X], xdst[WPF_X];      // packed (ppt | ppy<<6 | ppx<<15 | c8<<24), LDS byte offset (or -1: no item)
   int yloc[WPF_Y], ydst[WPF_Y];      // packed (rt | ry<<6 | rx<<15 | c<<24)
+  int xrel[WPF_X], yrel[WPF_Y];      // element offset of the item relative to the box origin
 #pragma unroll
   for (int u = 0; u < WPF_X; ++u) {
     const int item = u * 256 + t;
-    xdst[u] = -1; xloc[u] = 0;
+    xdst[u] = -1; xloc[u] = 0; xrel[u] = 0;
     if (item < totX) {
       const int pixel = g.magicC8 ? (int)__umulhi((unsigned)item, g.magicC8) : item;
       const int c8 = item - pixel * g.C8i;
@@ -1109,61 +1115,60 @@ __global__ __launch_bounds__(256) void k_wgrad_patch_pf(
       const int ppy = r / g.px; const int ppx = r - ppy * g.px;
       xloc[u] = ppt | (ppy << 6) | (ppx << 15) | (c8 << 24);
       xdst[u] = pixel * g.ppitch + c8 * 16;
+      xrel[u] = ((ppt * g.Hi + ppy) * g.Wi + ppx) * g.Cpi + c8 * 8;
     }
   }
 #pragma unroll
   for (int u = 0; u < WPF_Y; ++u) {
     const int item = u * 256 + t;
-    ydst[u] = -1; yloc[u] = 0;
+    ydst[u] = -1; yloc[u] = 0; yrel[u] = 0;
     if (item < totY) {
       const int row = g.magicNC ? (int)__umulhi((unsigned)item, g.magicNC) : item;
       const int c = item - row * g.NC;
       const int rt = row / g.byx; const int r = row - rt * g.byx;
       const int ry = r / g.bx; const int rx = r - ry * g.bx;
       yloc[u] = rt | (ry << 6) | (rx << 15) | (c << 24);
+      yrel[u] = ((rt * g.Ho + ry) * g.Wo + rx) * g.Cpo + n0 + c * 8;
       ydst[u] = (rt < g.bt) ? row * g.ypitch + c * 16 : -2;      // -2: row outside the box -> zeros
     }
   }
 
   float4 xa_[WPF_X], xb_[WPF_X], ya_[WPF_Y], yb_[WPF_Y];
-  int xfl = 0, yfl = 0;       // per item 2 bits: bit0 = loaded (inside the tensor), bit1 = upper half is padding
-  auto issue = [&](int box) {
+  int xfl = 0;                // per item 2 bits: bit0 = loaded (inside the tensor), bit1 = upper half is padding
+  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(src, g.x_bytes), yrs = make_rsrc(dy, g.y_bytes);
+  // Box being requested (scalars): clip index, output-box origin, input-patch origin, element offsets of the origins.
+  int q_t0 = 0, q_y0 = 0, q_x0 = 0, q_ot = 0, q_oh = 0, q_ow = 0, q_xbase = 0, q_ybase = 0, q_live = 0;
+  auto aim = [&](int box, bool live) {
     int b = box;
     const int xb = b % g.nbx; b /= g.nbx;
     const int yb = b % g.nby; b /= g.nby;
     const int tb = b % g.nbt; const int n = b / g.nbt;
-    const int t0 = tb * g.bt, y0 = yb * g.by, x0 = xb * g.bx;
-    const int ot = t0 * g.st + g.org_t, oh = y0 * g.sh + g.org_h, ow = x0 * g.sw + g.org_w;
-    xfl = 0; yfl = 0;
-#pragma unroll
-    for (int u = 0; u < WPF_X; ++u) {
-      xa_[u] = make_float4(0.f, 0.f, 0.f, 0.f); xb_[u] = xa_[u];
-      if (xdst[u] >= 0) {
-        const int st = ot + (xloc[u] & 63), sy = oh + ((xloc[u] >> 6) & 511), sx = ow + ((xloc[u] >> 15) & 511);
-        const int c8 = (xloc[u] >> 24) & 255;
-        if (((unsigned)st < (unsigned)g.Ti) && ((unsigned)sy < (unsigned)g.Hi) && ((unsigned)sx < (unsigned)g.Wi) &&
-            c8 * 2 < xcv4) {
-          const float* s = src + ((size_t)((n * g.Ti + st) * g.Hi + sy) * g.Wi + sx) * g.Cpi + c8 * 8;
-          xa_[u] = *(const float4*)s;
-          xfl |= 1 << (2 * u);
-          if (c8 * 2 + 1 < xcv4) xb_[u] = *(const float4*)(s + 4); else xfl |= 2 << (2 * u);
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < WPF_Y; ++u) {
-      ya_[u] = make_float4(0.f, 0.f, 0.f, 0.f); yb_[u] = ya_[u];
-      if (ydst[u] >= 0) {
-        const int ot_ = t0 + (yloc[u] & 63), oy_ = y0 + ((yloc[u] >> 6) & 511), ox_ = x0 + ((yloc[u] >> 15) & 511);
-        const int c = (yloc[u] >> 24) & 255;
-        if (ot_ < g.To && oy_ < g.Ho && ox_ < g.Wo && c * 2 < ycv4) {
-          const float* s = dy + ((size_t)((n * g.To + ot_) * g.Ho + oy_) * g.Wo + ox_) * g.Cpo + n0 + c * 8;
-          ya_[u] = *(const float4*)s;
-          yfl |= 1 << (2 * u);
-          if (c * 2 + 1 < ycv4) yb_[u] = *(const float4*)(s + 4);
-        }
-      }
-    }
+    q_t0 = tb * g.bt; q_y0 = yb * g.by; q_x0 = xb * g.bx;
+    q_ot = q_t0 * g.st + g.org_t; q_oh = q_y0 * g.sh + g.org_h; q_ow = q_x0 * g.sw + g.org_w;
+    q_xbase = (((n * g.Ti + q_ot) * g.Hi + q_oh) * g.Wi + q_ow) * g.Cpi;
+    q_ybase = (((n * g.To + q_t0) * g.Ho + q_y0) * g.Wo + q_x0) * g.Cpo;
+    q_live = live ? 1 : 0;
+  };
+  // Branch-free request of one item (out-of-range offset -> zeros, no memory traffic), so that the requests can be
+  // spread between the MFMA groups of the box in flight.
+  auto issue_x = [&](int u) {
+    const int st = q_ot + (xloc[u] & 63), sy = q_oh + ((xloc[u] >> 6) & 511), sx = q_ow + ((xloc[u] >> 15) & 511);
+    const int c8 = (xloc[u] >> 24) & 255;
+    const bool in = q_live && xdst[u] >= 0 && ((unsigned)st < (unsigned)g.Ti) && ((unsigned)sy < (unsigned)g.Hi) &&
+                    ((unsigned)sx < (unsigned)g.Wi) && c8 * 2 < xcv4;
+    const bool up = in && c8 * 2 + 1 < xcv4;
+    const unsigned off = (unsigned)(q_xbase + xrel[u]) * 4u;
+    xa_[u] = buf_load4(xrs, in ? off : MD_OOB);
+    xb_[u] = buf_load4(xrs, up ? off + 16u : MD_OOB);
+    xfl = (xfl & ~(3 << (2 * u))) | ((in ? 1 : 0) << (2 * u)) | ((in && !up ? 2 : 0) << (2 * u));
+  };
+  auto issue_y = [&](int u) {
+    const int ot_ = q_t0 + (yloc[u] & 63), oy_ = q_y0 + ((yloc[u] >> 6) & 511), ox_ = q_x0 + ((yloc[u] >> 15) & 511);
+    const int c = (yloc[u] >> 24) & 255;
+    const bool in = q_live && ydst[u] >= 0 && ot_ < g.To && oy_ < g.Ho && ox_ < g.Wo && c * 2 < ycv4;
+    const unsigned off = (unsigned)(q_ybase + yrel[u]) * 4u;
+    ya_[u] = buf_load4(yrs, in ? off : MD_OOB);
+    yb_[u] = buf_load4(yrs, (in && c * 2 + 1 < ycv4) ? off + 16u : MD_OOB);
   };
   auto commit = [&]() {
 #pragma unroll
@@ -1206,7 +1211,13 @@ __global__ __launch_bounds__(256) void k_wgrad_patch_pf(
 #else
 #define PH(i)
 #endif
-  if (box_beg < box_end) issue(box_beg);
+  if (box_beg < box_end) {
+    aim(box_beg, true);
+#pragma unroll
+    for (int u = 0; u < WPF_X; ++u) issue_x(u);
+#pragma unroll
+    for (int u = 0; u < WPF_Y; ++u) issue_y(u);
+  }
   PH(0);
   for (int box = box_beg; box < box_end; ++box) {
     __syncthreads();          // previous box fully consumed (first iteration: tables / scale in LDS)
@@ -1215,7 +1226,7 @@ __global__ __launch_bounds__(256) void k_wgrad_patch_pf(
     PH(2);
     __syncthreads();
     PH(3);
-    if (box + 1 < box_end) issue(box + 1);      // in flight during the MFMA phase below
+    aim(min(box + 1, box_end - 1), box + 1 < box_end);      // next box: requested item by item between the MFMA groups
     PH(4);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -1230,6 +1241,11 @@ __global__ __launch_bounds__(256) void k_wgrad_patch_pf(
       }
 #pragma unroll
       for (int a = 0; a < KTW; ++a) {
+        {
+          const int grp = s * KTW + a;          // 4*KTW >= 12 groups for the 7 + 5 items
+          if (grp < WPF_X) issue_x(grp);
+          else if (grp - WPF_X < WPF_Y) issue_y(grp - WPF_X);
+        }
         const bf16x8 ah = tr_read2(sP + xa + koff[a], sP + xb2 + koff[a]);
         const bf16x8 al = tr_read2(sP + g.lo_off + xa + koff[a], sP + g.lo_off + xb2 + koff[a]);
 #pragma unroll
@@ -1238,6 +1254,11 @@ __global__ __launch_bounds__(256) void k_wgrad_patch_pf(
           acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[a][j], 0, 0, 0);
           acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[a][j], 0, 0, 0);
         }
+        if (s * KTW + a < WPF_X + WPF_Y) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);      // this group's two requests,
+        __builtin_amdgcn_sched_group_barrier(0x008, 3 * NREP, 0);                                 // then its MFMAs
+        // (the scheduler fills groups bottom-up and would otherwise sink the requests to the END of the MFMA phase,
+        // where their latency is exposed at the next commit)
+        if (s * KTW + a == WPF_X + WPF_Y - 1) __builtin_amdgcn_sched_barrier(0);
       }
     }
     PH(5);
@@ -1344,6 +1365,11 @@ static bool wgrad_build(const MdConvDesc* d, WGeom* out, size_t* lds_bytes, int*
   g.magicC8 = g.C8i == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)g.C8i) + 1u;
   g.magicNC = g.NC == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)g.NC) + 1u;
   if (g.Cpi > PMAXC) return false;
+  {
+    const unsigned long long xb = (unsigned long long)d->N * g.Ti * g.Hi * g.Wi * g.Cpi * 4ull;
+    const unsigned long long yb = (unsigned long long)d->N * g.To * g.Ho * g.Wo * g.Cpo * 4ull;
+    g.x_bytes = xb < 0x80000000ull ? (unsigned)xb : 0u; g.y_bytes = yb < 0x80000000ull ? (unsigned)yb : 0u;   // 0: no buffer addressing
+  }
   const size_t cap = 160 * 1024;
   const size_t fixed = (size_t)2 * g.ylo_off + (size_t)PM * 8 + (size_t)PM * 4 + 2 * PMAXC * 4 + 1024;
   if (fixed + 4096 > cap) return false;
@@ -1375,6 +1401,10 @@ static bool wgrad_build(const MdConvDesc* d, WGeom* out, size_t* lds_bytes, int*
   off = (off + 15) & ~(size_t)15;
   g.off_scale = (int)off; off += (size_t)2 * PMAXC * 4;
   if (off > cap) return false;
+  if (getenv("MD_PLAN_PRINT"))
+    fprintf(stderr, "wgrad %d->%d k%d%d%d s%d%d%d out %dx%dx%d: box %dx%dx%d patch %dx%dx%d=%d C8i=%d nkt=%d ktw=%d nkg=%d nrep=%d nng=%d lds=%zu\n",
+            d->Cin, d->Cout, d->kt, d->kh, d->kw, d->st, d->sh, d->sw, g.To, g.Ho, g.Wo, g.bt, g.by, g.bx, g.pt, g.py, g.px, g.P,
+            g.C8i, g.nkt, g.ktw, g.nkg, g.nrep, g.nng, off);
   *out = g; *lds_bytes = off;
   return true;
 }
@@ -1382,7 +1412,7 @@ static bool wgrad_build(const MdConvDesc* d, WGeom* out, size_t* lds_bytes, int*
 static bool wgrad_use_pf(const WGeom& g) {
   static const int no_pf = getenv("MD_WGRAD_PF") && atoi(getenv("MD_WGRAD_PF")) == 0;
   static const int dbg = getenv("MD_DBG") ? atoi(getenv("MD_DBG")) : 0;
-  return !no_pf && !dbg && g.P * g.C8i <= WPF_X * 256 && PM * g.NC <= WPF_Y * 256 && g.pt < 64 && g.py < 512 && g.px < 512 &&
+  return !no_pf && !dbg && g.x_bytes && g.y_bytes && g.P * g.C8i <= WPF_X * 256 && PM * g.NC <= WPF_Y * 256 && g.pt < 64 && g.py < 512 && g.px < 512 &&
          g.bt < 64;
 }
 template <int KT, int NR>

@@ -80,6 +80,23 @@ def cpu_baseline(steps=2, warmup=1):
                       f"oracle/ on torch-CPU, anomaly mode off"}
 
 
+def pmc_traffic(dom):
+    """HBM bytes per launch of the dominant kernel family, from the newest committed PMC pass
+    (profiles/*_pmc_hbm_traffic.json, written by tools/pmc_traffic.sh + tools/pmc_traffic_parse.py: separate
+    FETCH_SIZE / WRITE_SIZE passes of this same bench, read bytes = 2 x FETCH_SIZE on gfx950).  None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")))
+    if not files:
+        return None, "no PMC pass committed"
+    fams = json.load(open(files[-1]))["families"]
+    sel = [v for k, v in fams.items() if k.startswith(dom)]
+    n = sum(v["launches_per_step"] for v in sel)
+    if not n:
+        return None, "kernel family not in " + os.path.basename(files[-1])
+    b = sum(v["read_bytes_per_step"] + v["write_bytes_per_step"] for v in sel)
+    return round(b / n), "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) from profiles/" + os.path.basename(files[-1])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,6 +198,7 @@ def main():
         else:
             dom, d_ms, d_n, d_fl = "k_wgrad_patch", w_ms, w_n, w_fl
         achieved = d_fl / (d_ms * 1e-3) / 1e12
+        traffic, traffic_note = pmc_traffic(dom)
         out = {
             "metric": "clips/sec (fwd+bwd) R2Plus1D T=21 128x128", "value": round(value, 2), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
@@ -191,7 +209,8 @@ def main():
                                    "forward+FocalLoss(gamma=2)+backward+clip_grad_norm(1.0)+AdamW(2e-4), BN in train mode",
                        "per_gpu_batch": B_PER_GPU, "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": round(PEAK_SPLIT_TFLOPS, 1), "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_SPLIT_TFLOPS, 4), "traffic": None, "kernel": dom,
+                         "frac": round(achieved / PEAK_SPLIT_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
+                         "kernel": dom,
                          "peak_note": "2500 TFLOP/s dense 16-bit MFMA / 3 products per multiply; achieved = algorithmic FLOPs",
                          "launches": int(d_n), "avg_launch_ms": round(d_ms / max(1, d_n), 5),
                          "alg_flop_per_launch": d_fl / max(1, d_n)},

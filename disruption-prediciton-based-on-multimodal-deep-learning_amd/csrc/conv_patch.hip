@@ -1456,7 +1456,12 @@ const WgradPlan* wgrad_lookup(const MdConvDesc* d) {
   if (wgrad_build(d, &g, &lds, &ns)) {
     // one slice (= one slab of partial sums) per resident workgroup: a single full round on the chip, and no more
     // slab traffic than that needs
-    int want = md_cdiv(256 * wgrad_wgs_per_cu(g, lds), g.nkg * g.nng);
+    // CUs to occupy.  The executor runs weight gradients on a side stream next to the BatchNorm-backward / data-gradient
+    // chain (plan.hip); leaving part of the chip to that chain measured best at 160 of 256 (96: 992, 128: 1088,
+    // 160: 1097, 192: 1085, 256: 1068 clips/s); with the side stream switched off the kernel takes the whole chip.
+    static const int side_off = getenv("MD_WGRAD_STREAM") && atoi(getenv("MD_WGRAD_STREAM")) == 0;
+    static const int fill = getenv("MD_WGRAD_FILL") ? atoi(getenv("MD_WGRAD_FILL")) : (side_off ? 256 : 160);
+    int want = md_cdiv(fill * wgrad_wgs_per_cu(g, lds), g.nkg * g.nng);
     if (want > g.nboxes) want = g.nboxes;
     if (want < 1) want = 1;
     g.boxes_per_wg = md_cdiv(g.nboxes, want);

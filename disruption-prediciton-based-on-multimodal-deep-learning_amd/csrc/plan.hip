@@ -51,7 +51,52 @@ struct MdPlan {
   size_t part_floats;
   int feat_dim;
   int bwd_p;   // gradient buffer currently holding dZ
+  // Weight gradients run on a second (low-priority) stream, concurrently with the BatchNorm-backward / data-gradient
+  // chain that the next unit waits for: the chain is HBM-bound, the weight gradient MFMA/VALU-bound, and one workgroup
+  // of each fits a CU together.  ready = d_raw of the unit is complete (main -> side); done[b] = the last weight
+  // gradient reading gradient buffer b has finished (side -> main, awaited before b is overwritten).
+  hipStream_t side = nullptr;
+  hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_done[4] = {nullptr, nullptr, nullptr, nullptr}, ev_join = nullptr;
+  bool done_pending[4] = {false, false, false, false};
+  int ready_ix = 0;
+  bool side_used = false;     // work was queued on the side stream since the last join
+  int side_state = 0;         // 0 not tried, 1 available, -1 unavailable (then everything stays on the caller's stream)
 };
+
+static bool side_stream(MdPlan* P) {
+  if (P->side_state) return P->side_state > 0;
+  static const int off = getenv("MD_WGRAD_STREAM") && atoi(getenv("MD_WGRAD_STREAM")) == 0;
+  P->side_state = -1;
+  if (off) return false;
+  int lo = 0, hi = 0;
+  if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (hipStreamCreateWithPriority(&P->side, hipStreamNonBlocking, lo) != hipSuccess) { (void)hipGetLastError(); return false; }
+  bool ok = true;
+  for (auto& e : P->ev_ready) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+  for (auto& e : P->ev_done) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&P->ev_join, hipEventDisableTiming) == hipSuccess;
+  if (!ok) { (void)hipGetLastError(); return false; }
+  P->side_state = 1;
+  return true;
+}
+// the caller's stream must not overwrite gradient buffer b while a weight gradient on the side stream still reads it
+static int await_buffer(MdPlan* P, int b, void* stream) {
+  if (b >= 0 && P->side_state > 0 && P->done_pending[b]) {
+    if (hipStreamWaitEvent((hipStream_t)stream, P->ev_done[b], 0) != hipSuccess) return MD_ERR_LAUNCH;
+    P->done_pending[b] = false;
+  }
+  return MD_OK;
+}
+// everything queued on the side stream becomes visible to the caller's stream
+static int join_side(MdPlan* P, void* stream) {
+  if (P->side_state > 0 && P->side_used) {
+    if (hipEventRecord(P->ev_join, P->side) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, P->ev_join, 0) != hipSuccess)
+      return MD_ERR_LAUNCH;
+    P->side_used = false;
+    for (bool& d : P->done_pending) d = false;
+  }
+  return MD_OK;
+}
 
 static int conv_out(int i, int k, int s, int p) { return (i + 2 * p - k) / s + 1; }
 
@@ -150,6 +195,13 @@ extern "C" int md_plan_create(int32_t B, int32_t T, int32_t H, int32_t W, const 
 extern "C" void md_plan_destroy(MdPlan* p) {
   if (!p) return;
   for (hipEvent_t e : p->prof.pool) (void)hipEventDestroy(e);
+  if (p->side_state > 0) {
+    (void)hipStreamSynchronize(p->side);
+    for (hipEvent_t e : p->ev_ready) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->ev_done) if (e) (void)hipEventDestroy(e);
+    if (p->ev_join) (void)hipEventDestroy(p->ev_join);
+    (void)hipStreamDestroy(p->side);
+  }
   delete p;
 }
 extern "C" int32_t md_plan_num_units(const MdPlan* p) { return p ? (int32_t)p->units.size() : 0; }
@@ -299,9 +351,21 @@ static int unit_backward(MdPlan* P, float* ws, int ui, int gb, int dxb, int accu
     RC(md_bn_bwd_apply(G, &mainv, nullptr, 1.f, st, st + u.Cp, ws + P->coef_off, u.rows, u.d.Cout, G, nullptr, stream));
   }
   MdActView in = unit_in_view(P, ws, ui);
-  { ProfScope ps(P, KC_WGRAD, unit_flops(u), stream);
-    RC(md_conv_wgrad(&u.d, &in, G, dw[ui], ws + P->slab_off, stream)); }
+  if (side_stream(P)) {
+    // d_raw (G) is complete on the caller's stream here; the weight gradient reads it from the side stream
+    hipEvent_t ready = P->ev_ready[P->ready_ix]; P->ready_ix ^= 1;
+    if (hipEventRecord(ready, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(P->side, ready, 0) != hipSuccess)
+      return MD_ERR_LAUNCH;
+    { ProfScope ps(P, KC_WGRAD, unit_flops(u), P->side);
+      RC(md_conv_wgrad(&u.d, &in, G, dw[ui], ws + P->slab_off, P->side)); }
+    if (hipEventRecord(P->ev_done[gb], P->side) != hipSuccess) return MD_ERR_LAUNCH;
+    P->done_pending[gb] = true; P->side_used = true;
+  } else {
+    ProfScope ps(P, KC_WGRAD, unit_flops(u), stream);
+    RC(md_conv_wgrad(&u.d, &in, G, dw[ui], ws + P->slab_off, stream));
+  }
   if (dxb >= 0) {
+    RC(await_buffer(P, dxb, stream));
     ProfScope ps(P, KC_DGRAD, unit_flops(u), stream);
     RC(md_conv_dgrad(&u.d, G, ws + u.wd_off, ws + P->g_off[dxb], accumulate, stream));
   }
@@ -322,6 +386,8 @@ static int block_backward(MdPlan* P, float* ws, const Block& b, const float* con
   float* Gp = ws + P->g_off[p];
   RC(md_bn_bwd_reduce(Gp, &mainv, &skipv, P->alpha, st, st + t2.Cp, t2.rows, t2.d.Cout, ws + P->part_off, stream));
   RC(md_bn_bwd_finalize(ws + P->part_off, nb, t2.d.Cout, t2.rows, dgamma[b.c2t], dbeta[b.c2t], ws + P->coef_off, stream));
+  RC(await_buffer(P, a, stream));
+  RC(await_buffer(P, p, stream));
   RC(md_bn_bwd_apply(Gp, &mainv, &skipv, P->alpha, st, st + t2.Cp, ws + P->coef_off, t2.rows, t2.d.Cout,
                      ws + P->g_off[a], Gp, stream));
   RC(unit_backward(P, ws, b.c2t, a, bb, 0, true, w, dw, dgamma, dbeta, stream));
@@ -349,6 +415,7 @@ extern "C" int md_plan_backward_range(MdPlan* P, const float* dfeat, const float
     if (!dfeat) return MD_ERR_NULL;
     P->bwd_p = 0;
     const ZT& zl = P->z.back();
+    RC(await_buffer(P, 0, stream));
     RC(md_avgpool_bwd(dfeat, P->B, zl.C, zl.rows / P->B, ws + P->g_off[0], stream));
   }
   for (int bi = (int)P->blocks.size() - 1; bi >= 0; --bi) {
@@ -361,7 +428,7 @@ extern "C" int md_plan_backward_range(MdPlan* P, const float* dfeat, const float
     RC(unit_backward(P, ws, 1, p, q, 0, false, w, dw, dgamma, dbeta, stream));
     RC(unit_backward(P, ws, 0, q, -1, 0, false, w, dw, dgamma, dbeta, stream));
   }
-  return MD_OK;
+  return join_side(P, stream);        // the weight gradients of this range are ordered before whatever follows
 }
 
 extern "C" int md_plan_backward(MdPlan* P, const float* dfeat, const float* const* w, const float* const* gamma,

@@ -195,7 +195,7 @@ extern "C" int md_plan_create(int32_t B, int32_t T, int32_t H, int32_t W, const 
 extern "C" void md_plan_destroy(MdPlan* p) {
   if (!p) return;
   for (hipEvent_t e : p->prof.pool) (void)hipEventDestroy(e);
-  if (p->side_state > 0) {
+  if (p->side) {
     (void)hipStreamSynchronize(p->side);
     for (hipEvent_t e : p->ev_ready) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : p->ev_done) if (e) (void)hipEventDestroy(e);
@@ -236,6 +236,20 @@ struct ProfScope {
   }
   ~ProfScope() { if (on) (void)hipEventRecord(P->prof.pool[2 * idx + 1], s); }
 };
+
+// 0: queue the weight gradients on the caller's stream (serial schedule), 1: use the side stream (default when the
+// runtime provides one).  Both schedules launch the same kernels and give bit-identical results.
+extern "C" int md_plan_use_side_stream(MdPlan* P, int enable) {
+  if (!P) return MD_ERR_NULL;
+  if (!enable) {
+    if (P->side_state > 0) { if (hipStreamSynchronize(P->side) != hipSuccess) return MD_ERR_LAUNCH; P->side_state = -2; }
+    else if (P->side_state == 0) P->side_state = -3;           // never create it
+  } else {
+    if (P->side_state == -2) P->side_state = 1;                 // re-enable the existing stream
+    else if (P->side_state == -3) P->side_state = 0;            // create on next use
+  }
+  return MD_OK;
+}
 
 extern "C" int md_plan_profile_enable(MdPlan* P, int enable) {
   if (!P) return MD_ERR_NULL;

@@ -48,6 +48,10 @@ class TrunkPlan:
         except Exception:
             pass
 
+    def use_side_stream(self, on: bool) -> None:
+        """Backward schedule (md_plan_use_side_stream): concurrent weight gradients (default) or one serial stream."""
+        N.check(N.lib().md_plan_use_side_stream(self._h, int(bool(on))), "md_plan_use_side_stream")
+
     def profile_enable(self, on: bool) -> None:
         N.check(N.lib().md_plan_profile_enable(self._h, int(on)), "md_plan_profile_enable")
 

@@ -216,6 +216,11 @@ int md_plan_backward_range(MdPlan* p, const float* dfeat, const float* const* w,
                            float* const* dw, float* const* dgamma, float* const* dbeta,
                            void* workspace, int32_t stage_hi, int32_t stage_lo, void* stream);
 int32_t md_plan_feat_dim(const MdPlan* p);
+/* Backward schedule: with enable != 0 (default) the weight gradient of a unit is queued on an internal low-priority
+ * stream as soon as the unit's output gradient is final, concurrently with the BatchNorm-backward / data-gradient chain
+ * on the caller's stream; every md_plan_backward_range call joins the two before returning to the caller's stream
+ * order.  enable == 0 queues everything on the caller's stream.  Same kernels, bit-identical results. */
+int md_plan_use_side_stream(MdPlan* p, int32_t enable);
 /* Measurement aid (bench.py roofline leg): bracket every convolution launch of the plan with HIP events on
  * the launch stream.  md_plan_profile_read sums, per kernel class (0 conv forward, 1 conv data-gradient,
  * 2 conv weight-gradient), the measured milliseconds, the launch count and the algorithmic FLOPs

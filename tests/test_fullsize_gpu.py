@@ -76,3 +76,34 @@ def test_fullsize_forward_backward(reference, exact):
     # oracle itself sits `cpu_noise` (~5e-3) away from its fp64 evaluation.  Hold the HIP path to the same order.
     assert np.median(errs) < max(2e-3, 4.0 * float(np.median(cpu_noise))), (np.median(errs), np.median(cpu_noise))
     assert worst < max(1e-2, 5.0 * max(cpu_noise)), (worst, max(cpu_noise))
+
+
+def test_side_stream_schedule_is_bit_identical_to_serial():
+    """Backward with weight gradients on the side stream (default) vs everything on one stream: same kernels, so every
+    gradient must be bit-identical -- a gradient buffer overwritten before its weight gradient has read it (the hazard
+    the events guard against) would show up here.  Three repetitions per schedule, BASELINE shape, B=8."""
+    model = R2Plus1DClassifier(input_size=(3, T, S, S), num_classes=2, layer_sizes=LS, alpha=ALPHA)
+    params, bufs = orc.synth_state(LS, SEED, ALPHA)
+    sd = dict(params); sd.update(bufs)
+    model.load_state_dict(sd, strict=True)
+    model.to(DEV).train()
+    loss_fn = FocalLoss(weight=torch.ones(2), gamma=2.0)
+    x = orc.synth_clip(8, T, S, SEED + 1).to(DEV); y = orc.synth_labels(8, SEED + 1).to(DEV)
+
+    def grads(side):
+        out = []
+        for _ in range(3):
+            model.zero_grad(set_to_none=True)
+            logits = model(x)
+            for plan in model.res2plus1d._plans.values():
+                plan.use_side_stream(side)
+            loss_fn(logits, y).backward()
+            torch.cuda.synchronize()
+            out.append([p.grad.detach().clone() for p in model.parameters()])
+        return out
+
+    serial = grads(False)
+    side = grads(True)
+    for run in serial[1:] + side:
+        for a, b in zip(serial[0], run):
+            assert torch.equal(a, b)

@@ -114,18 +114,18 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned o
 // sG[pixel] = global pixel index or -1 (outside the tensor: zeros = the convolution's zero padding).
 // Channels c0 .. c0 + 4*cvalid4 are read (cvalid4 = valid float4 units from c0); chunks past that are zero.
 // With `prologue`, value = leaky(x*scale[c] + shift[c]) ("BN-on-read") before the bf16 hi/lo split.
-template <bool F16>
+template <bool F16, int NT = 256>
 __device__ __forceinline__ void stage_image(__amdgpu_buffer_rsrc_t src, int Cpitch, int c0, int cvalid4,
                                             const int* sG, int npix, int C8, unsigned magic, char* img, int pitch,
                                             int lo_off, bool prologue, const float* sScale, const float* sShift,
                                             float pslope, int t) {
   const int total = npix * C8;
-  for (int base = 0; base < total; base += 256 * 4) {
+  for (int base = 0; base < total; base += NT * 4) {
     float4 va[4], vb[4];
     int pix[4], c8s[4];      // pix: pixel | 0x20000000 (outside the tensor: zeros, no prologue); -1 = no item
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int item = min(base + u * 256 + t, total - 1);
+      const int item = min(base + u * NT + t, total - 1);
       const int pixel = mdiv(item, magic);
       const int c8 = item - pixel * C8;
       const int gp = sG[pixel];
@@ -133,7 +133,7 @@ __device__ __forceinline__ void stage_image(__amdgpu_buffer_rsrc_t src, int Cpit
       const unsigned off = in ? (unsigned)(gp * Cpitch + c0 + c8 * 8) * 4u : MD_OOB;
       va[u] = buf_load4(src, off);
       vb[u] = buf_load4(src, (in && c8 * 2 + 1 < cvalid4) ? off + 16u : MD_OOB);
-      pix[u] = base + u * 256 + t < total ? (pixel | (in ? 0 : 0x20000000)) : -1;
+      pix[u] = base + u * NT + t < total ? (pixel | (in ? 0 : 0x20000000)) : -1;
       c8s[u] = c8;
     }
 #pragma unroll
@@ -165,8 +165,10 @@ __device__ __forceinline__ f32x4 mma(uint4 a, uint4 b, f32x4 c) {
 
 // F16 = true: forward convolution, operands split into fp16 halves (activations/weights are O(1) quantities);
 // F16 = false: data gradient, operands split into bf16 halves (gradients need bf16's exponent range).
-template <bool F16, bool STRIDED, int NREP>
-__global__ __launch_bounds__(256) void k_conv_patch(
+// W8: eight waves (512 threads) on the same 128-pixel box -- wave = (row pair wr, column half wc); used where LDS allows
+// only one workgroup per CU, so that two waves per SIMD can overlap each other's staging, LDS and matrix phases.
+template <bool F16, bool STRIDED, int NREP, bool W8 = false>
+__global__ __launch_bounds__(W8 ? 512 : 256) void k_conv_patch(
     PGeom g, const float* __restrict__ src, const float* __restrict__ pscale, const float* __restrict__ pshift,
     float pslope, const uint4* __restrict__ wp, float* __restrict__ dst, float* __restrict__ stat_partial,
     int accumulate, int n_per_blk) {
@@ -180,7 +182,11 @@ __global__ __launch_bounds__(256) void k_conv_patch(
   float* sShift = sScale + PMAXC;
 
   const int t = threadIdx.x;
+  constexpr int NT = W8 ? 512 : 256;
+  constexpr int NW = W8 ? (NREP + 1) / 2 : NREP;          // column tiles per wave
   const int lane = t & 63, wave = t >> 6;
+  const int wr = wave & 3, wc = wave >> 2;                // rows 32*wr .. +31; column half (W8 only)
+  const int j0 = wc ? NREP - NW : 0;                      // first column tile of this wave (odd NREP: the halves overlap by one)
   const int li = lane & 15, lg = lane >> 4;
   const int n0 = blockIdx.y * n_per_blk;
   const int ncols = min(n_per_blk, g.N16 - n0);
@@ -207,7 +213,7 @@ __global__ __launch_bounds__(256) void k_conv_patch(
   }
 
   // ---- tables
-  for (int p = t; p < g.P; p += 256) {
+  for (int p = t; p < g.P; p += NT) {
     const int ppt = mdiv(p, g.m_pyx); const int r = p - ppt * g.pyx;
     const int ppy = mdiv(r, g.m_px); const int ppx = r - ppy * g.px;
     int st, sy, sx;
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(256) void k_conv_patch(
     ri.w = 0;
     sR[t] = ri;
   }
-  for (int q = t; q < g.nstages * 8; q += 256) {
+  for (int q = t; q < g.nstages * 8; q += NT) {
     int ko = STRIDED ? -1 : 0;              // strided: -1 marks a K-padding chunk (reads the zero pixel)
     if (q < g.Kc8) {
       const int tap = mdiv(q, g.magicC8); const int c8 = q - tap * g.C8;
@@ -238,12 +244,12 @@ __global__ __launch_bounds__(256) void k_conv_patch(
     }
     sK[q] = ko;
   }
-  if (prologue) for (int c = t; c < g.Cps; c += 256) { const int cs = g.pack2 ? (c & 3) : c; sScale[c] = pscale[cs]; sShift[c] = pshift[cs]; }
+  if (prologue) for (int c = t; c < g.Cps; c += NT) { const int cs = g.pack2 ? (c & 3) : c; sScale[c] = pscale[cs]; sShift[c] = pshift[cs]; }
 
   // ---- B tile prefetch (registers): [stage][hi|lo][N16][8 chunks] uint4, this block's rows n0..n0+ncols.
   // Loads are unconditional (clamped index) so that the prefetch stays a straight run of global loads.
   const int bchunks = ncols * 8;                 // per half
-  constexpr int NB = (NREP + 1) / 2;             // 16-byte chunks per thread per half (NREP*16*8 / 256)
+  constexpr int NB = (NREP * 128 + NT - 1) / NT;   // 16-byte chunks per thread per half (NREP*16*8 / threads)
   uint4 rb[2][NB];
   auto load_b = [&](int kb) {
 #pragma unroll
@@ -251,7 +257,7 @@ __global__ __launch_bounds__(256) void k_conv_patch(
       const uint4* base = wp + ((size_t)(kb * 2 + h) * g.N16 + n0) * 8;
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
-        const int c = t + 256 * i;
+        const int c = t + NT * i;
         const uint4 v = base[min(c, bchunks - 1)];     // columns past ncols get copies of a valid one; never stored
         rb[h][i] = v;
       }
@@ -262,18 +268,18 @@ __global__ __launch_bounds__(256) void k_conv_patch(
 
   // ---- stage the patch: global 32 B per lane -> (BN+act) -> split -> 16 B hi + 16 B lo
   if (!(dbg & 1))
-    stage_image<F16>(make_rsrc(src, g.src_bytes), g.Cps, 0, g.Cps >> 2, sG, g.P, g.C8, g.magicC8, sP, g.ppitch, g.lo_off, prologue, sScale,
+    stage_image<F16, NT>(make_rsrc(src, g.src_bytes), g.Cps, 0, g.Cps >> 2, sG, g.P, g.C8, g.magicC8, sP, g.ppitch, g.lo_off, prologue, sScale,
                      sShift, pslope, t);
   if (STRIDED) {
-    for (int i = t * 16; i < g.ppitch; i += 256 * 16) {
+    for (int i = t * 16; i < g.ppitch; i += NT * 16) {
       *(uint4*)(sP + g.zero_off + i) = make_uint4(0, 0, 0, 0);
       *(uint4*)(sP + g.lo_off + g.zero_off + i) = make_uint4(0, 0, 0, 0);
     }
   }
 
   // per-lane row offsets of this wave's two 16-row slabs
-  const int rp0 = sR[wave * 32 + li].x, rp1 = sR[wave * 32 + 16 + li].x;
-  const int rc0 = sR[wave * 32 + li].z, rc1 = sR[wave * 32 + 16 + li].z;     // packed numerators (strided dgrad)
+  const int rp0 = sR[wr * 32 + li].x, rp1 = sR[wr * 32 + 16 + li].x;
+  const int rc0 = sR[wr * 32 + li].z, rc1 = sR[wr * 32 + 16 + li].z;     // packed numerators (strided dgrad)
   auto strided_off = [&](int rc, int tc) -> int {
     if (rc < 0 || tc < 0) return g.zero_off;
     const int pk = rc - (tc & 0xffffff);
@@ -282,11 +288,11 @@ __global__ __launch_bounds__(256) void k_conv_patch(
     return ok ? ((ct * g.py + cy) * g.px + cx) * g.ppitch + ((tc >> 24) & 0xff) * 16 : g.zero_off;
   };
 
-  f32x4 acc[2][NREP];
+  f32x4 acc[2][NW];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int j = 0; j < NREP; ++j) acc[a][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NW; ++j) acc[a][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int blo = n_per_blk * PB_PITCH;    // lo half of the B tile
   // Software pipeline over the k32 steps (two per 64-k stage): the A fragments of step q+1 (they live in the patch,
@@ -302,7 +308,7 @@ __global__ __launch_bounds__(256) void k_conv_patch(
     f[0] = *(const uint4*)(sP + o0); f[1] = *(const uint4*)(sP + g.lo_off + o0);
     f[2] = *(const uint4*)(sP + o1); f[3] = *(const uint4*)(sP + g.lo_off + o1);
   };
-  const char* bbase = sB + li * PB_PITCH + lg * 16;
+  const char* bbase = sB + (j0 * 16 + li) * PB_PITCH + lg * 16;
   int ko_next = 0;                         // K offset of step q+1 while step q runs
   if (nsteps) {
     __syncthreads();                       // patch staged
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(256) void k_conv_patch(
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
-        const int c = t + 256 * i;
+        const int c = t + NT * i;
         if (c < n_per_blk * 8 && !((dbg & 16) && kb > 0)) *(uint4*)(sB + h * blo + (c >> 3) * PB_PITCH + (c & 7) * 16) = rb[h][i];
       }
     __syncthreads();
@@ -335,11 +341,11 @@ __global__ __launch_bounds__(256) void k_conv_patch(
       }
       const uint4 ah0 = fa[s][0], al0 = fa[s][1], ah1 = fa[s][2], al1 = fa[s][3];
 #pragma unroll
-      for (int j = 0; j < NREP; ++j) {
-        const int cur = (s * NREP + j) & 1;
-        const bool more = j + 1 < NREP || s == 0;      // next column tile (of this step, or tile 0 of the second step)
+      for (int j = 0; j < NW; ++j) {
+        const int cur = (s * NW + j) & 1;
+        const bool more = j + 1 < NW || s == 0;        // next column tile (of this step, or tile 0 of the second step)
         if (more) {
-          const int jn = j + 1 < NREP ? j + 1 : 0, sn = j + 1 < NREP ? s : 1;
+          const int jn = j + 1 < NW ? j + 1 : 0, sn = j + 1 < NW ? s : 1;
           const char* bp = bbase + jn * 16 * PB_PITCH + sn * 64;
           fb[cur ^ 1][0] = *(const uint4*)bp; fb[cur ^ 1][1] = *(const uint4*)(bp + blo);
         }
@@ -368,16 +374,18 @@ __global__ __launch_bounds__(256) void k_conv_patch(
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int gi = sR[wave * 32 + a * 16 + lg * 4 + r].y;
-      goff[a][r] = gi >= 0 ? (unsigned)(gi * g.Cpd + n0 + li) * 4u : MD_OOB;
+      const int gi = sR[wr * 32 + a * 16 + lg * 4 + r].y;
+      goff[a][r] = gi >= 0 ? (unsigned)(gi * g.Cpd + n0 + j0 * 16 + li) * 4u : MD_OOB;
       gw[a][r] = gi >= 0 ? 1.f : 0.f;
     }
   __syncthreads();
   float* red = (float*)sP;   // [4 waves][2][PNREP*16]
   const __amdgpu_buffer_rsrc_t drs = make_rsrc(dst, (dbg & 4) ? 0u : g.dst_bytes);
 #pragma unroll
-  for (int j = 0; j < NREP; ++j) {
-    const bool colok = n0 + j * 16 + li < g.Cpd;
+  for (int j = 0; j < NW; ++j) {
+    // (W8, odd NREP: the second half's first tile is also the first half's last -- computed twice, written and counted once)
+    const bool dup = W8 && (NREP & 1) && wc == 1 && j == 0;
+    const bool colok = !dup && n0 + (j0 + j) * 16 + li < g.Cpd;
     float s1 = 0.f, s2 = 0.f;
     float prev[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     if (accumulate) {
@@ -399,9 +407,9 @@ __global__ __launch_bounds__(256) void k_conv_patch(
     if (stat_partial != nullptr) {
       s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
       s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-      if (lg == 0) {
-        red[(wave * 2 + 0) * (PNREP * 16) + j * 16 + li] = s1;
-        red[(wave * 2 + 1) * (PNREP * 16) + j * 16 + li] = s2;
+      if (lg == 0 && !dup) {
+        red[(wr * 2 + 0) * (PNREP * 16) + (j0 + j) * 16 + li] = s1;
+        red[(wr * 2 + 1) * (PNREP * 16) + (j0 + j) * 16 + li] = s2;
       }
     }
   }
@@ -772,35 +780,43 @@ static int patch_launch_one(const PatchPlan* p, const PGeom& g, size_t lds, cons
   }
   const int npb = md_round_up(md_cdiv(g.N16, nchunks), 16);
   dim3 grid(boxes, md_cdiv(g.N16, npb));
+  {   // experiment: MD_LDS_PAD_KB forces a lower occupancy (how much do two workgroups per CU buy?)
+    static const int padkb = getenv("MD_LDS_PAD_KB") ? atoi(getenv("MD_LDS_PAD_KB")) : 0;
+    if (padkb && lds + (size_t)padkb * 1024 <= 160 * 1024) lds += (size_t)padkb * 1024; else if (padkb) lds = 160 * 1024;
+  }
   static const int dbg = getenv("MD_DBG") ? atoi(getenv("MD_DBG")) : 0;
   accumulate = (accumulate & 1) | ((dbg & 0xff) << 8);
   const int nrep = npb / 16;
-#define LAUNCH_PATCH(F16_, STR_, NR_)                                                                                   \
+  // eight waves on the box when LDS leaves room for one workgroup per CU only (then nothing else would overlap)
+  static const int w8_env = getenv("MD_PATCH_W8") ? atoi(getenv("MD_PATCH_W8")) : 1;
+  const bool w8 = w8_env && !g.strided && nrep >= 2 && (lds > 80 * 1024 || w8_env == 2);
+#define LAUNCH_PATCH(F16_, STR_, NR_, W8_)                                                                              \
   do {                                                                                                                  \
     static bool set_ = false;                                                                                           \
     if (!set_) {                                                                                                        \
-      if (hipFuncSetAttribute((const void*)k_conv_patch<F16_, STR_, NR_>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                              160 * 1024) != hipSuccess) return MD_ERR_LAUNCH;                                          \
+      if (hipFuncSetAttribute((const void*)k_conv_patch<F16_, STR_, NR_, W8_>,                                          \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)                    \
+        return MD_ERR_LAUNCH;                                                                                           \
       set_ = true;                                                                                                      \
     }                                                                                                                   \
-    MD_KLAUNCH((k_conv_patch<F16_, STR_, NR_>), grid, dim3(256), lds, s, g, src, ps, psh, slope,                \
-                       (const uint4*)wp, dst, stat, accumulate, npb);                                                   \
+    MD_KLAUNCH((k_conv_patch<F16_, STR_, NR_, W8_>), grid, dim3(W8_ ? 512 : 256), lds, s, g, src, ps, psh, slope,       \
+               (const uint4*)wp, dst, stat, accumulate, npb);                                                           \
   } while (0)
-#define LAUNCH_PATCH_NR(F16_, STR_)                                                                                     \
+#define LAUNCH_PATCH_NR(F16_, STR_, W8_)                                                                                \
   switch (nrep) {                                                                                                       \
-    case 1: LAUNCH_PATCH(F16_, STR_, 1); break;                                                                         \
-    case 2: LAUNCH_PATCH(F16_, STR_, 2); break;                                                                         \
-    case 3: LAUNCH_PATCH(F16_, STR_, 3); break;                                                                         \
-    case 4: LAUNCH_PATCH(F16_, STR_, 4); break;                                                                         \
-    case 5: LAUNCH_PATCH(F16_, STR_, 5); break;                                                                         \
-    case 6: LAUNCH_PATCH(F16_, STR_, 6); break;                                                                         \
-    case 7: LAUNCH_PATCH(F16_, STR_, 7); break;                                                                         \
-    case 8: LAUNCH_PATCH(F16_, STR_, 8); break;                                                                         \
-    default: LAUNCH_PATCH(F16_, STR_, 9); break;                                                                        \
+    case 1: LAUNCH_PATCH(F16_, STR_, 1, false); break;                                                                  \
+    case 2: LAUNCH_PATCH(F16_, STR_, 2, W8_); break;                                                                    \
+    case 3: LAUNCH_PATCH(F16_, STR_, 3, W8_); break;                                                                    \
+    case 4: LAUNCH_PATCH(F16_, STR_, 4, W8_); break;                                                                    \
+    case 5: LAUNCH_PATCH(F16_, STR_, 5, W8_); break;                                                                    \
+    case 6: LAUNCH_PATCH(F16_, STR_, 6, W8_); break;                                                                    \
+    case 7: LAUNCH_PATCH(F16_, STR_, 7, W8_); break;                                                                    \
+    case 8: LAUNCH_PATCH(F16_, STR_, 8, W8_); break;                                                                    \
+    default: LAUNCH_PATCH(F16_, STR_, 9, W8_); break;                                                                   \
   }
-  if (!p->dgrad) { LAUNCH_PATCH_NR(true, false); }
-  else if (!g.strided) { LAUNCH_PATCH_NR(false, false); }
-  else { LAUNCH_PATCH_NR(false, true); }
+  if (!p->dgrad) { if (w8) { LAUNCH_PATCH_NR(true, false, true); } else { LAUNCH_PATCH_NR(true, false, false); } }
+  else if (!g.strided) { if (w8) { LAUNCH_PATCH_NR(false, false, true); } else { LAUNCH_PATCH_NR(false, false, false); } }
+  else { LAUNCH_PATCH_NR(false, true, false); }
   MD_CHECK_LAUNCH();
   return MD_OK;
 }

@@ -175,13 +175,11 @@ __global__ __launch_bounds__(256) void k_bn_bwd(const float* __restrict__ dA, Vi
     const float4 mu = *(const float4*)(mean + w.c4 * 4), is = *(const float4*)(invstd + w.c4 * 4);
     float4 c1, c2;
     if (APPLY) { c1 = *(const float4*)(coef + w.c4 * 4); c2 = *(const float4*)(coef + Cp + w.c4 * 4); }
-    for (int64_t row = w.beg + w.r; row < w.end; row += w.nr) {
-      const size_t o = ((size_t)row * C4 + w.c4) * 4;
-      const float4 raw = *(const float4*)(main.p + o);
+    // one row: same arithmetic and the same accumulation order whatever the unrolling below
+    auto one = [&](size_t o, float4 raw, float4 d, float4 sraw) {
       const float4 pre = pre_of(main, km, raw);
-      float4 d = *(const float4*)(dA + o);
       if (has_skip) {
-        const float4 sv = act_of(skip, pre_of(skip, ks, *(const float4*)(skip.p + o)));
+        const float4 sv = act_of(skip, pre_of(skip, ks, sraw));
         const float4 sum = add4(sv, act_of(main, pre));
         d = mul4(d, make_float4(md_dleaky(sum.x, alpha), md_dleaky(sum.y, alpha), md_dleaky(sum.z, alpha), md_dleaky(sum.w, alpha)));
         if (APPLY) *(float4*)(dS + o) = d;
@@ -199,6 +197,25 @@ __global__ __launch_bounds__(256) void k_bn_bwd(const float* __restrict__ dA, Vi
         a1 = add4(a1, gq);
         a2 = add4(a2, mul4(gq, xh));
       }
+    };
+    // four rows per trip: 8-12 independent 16-byte loads in flight per lane (the pass is HBM-bound)
+    int64_t row = w.beg + w.r;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (; row + 3 * (int64_t)w.nr < w.end; row += 4 * (int64_t)w.nr) {
+      size_t o[4]; float4 raw[4], d[4], sk[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        o[u] = ((size_t)(row + u * (int64_t)w.nr) * C4 + w.c4) * 4;
+        raw[u] = *(const float4*)(main.p + o[u]);
+        d[u] = *(const float4*)(dA + o[u]);
+        sk[u] = has_skip ? *(const float4*)(skip.p + o[u]) : z4;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) one(o[u], raw[u], d[u], sk[u]);
+    }
+    for (; row < w.end; row += w.nr) {
+      const size_t o = ((size_t)row * C4 + w.c4) * 4;
+      one(o, *(const float4*)(main.p + o), *(const float4*)(dA + o), has_skip ? *(const float4*)(skip.p + o) : z4);
     }
   }
   if (!APPLY) {

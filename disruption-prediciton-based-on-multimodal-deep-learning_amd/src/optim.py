@@ -34,39 +34,65 @@ class ClipAdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, step=0))
         self.max_norm = max_norm
         self.last_grad_norm: Optional[torch.Tensor] = None      # device scalar of the most recent step (no host sync)
-        self._cache = {}                                         # group index -> (key, tensors_dev, chunks_dev, nchunks, partial)
+        self._cache = {}                                         # group index -> tables (see _tables)
 
     # ------------------------------------------------------------------ tables
+    _RING = 4      # pinned staging buffers per group: the host may run this many table refreshes ahead of the device
+
     def _tables(self, gi: int, group):
+        """Device tables for one parameter group: (key, tensor table, chunk table, #chunks, scratch).
+
+        The chunk table depends on the parameter sizes only.  The tensor table holds raw pointers; gradient tensors are
+        re-created by autograd every step and some change address, so the table is refreshed whenever a pointer moved --
+        through pinned staging buffers and an asynchronous copy on the current stream, never a host synchronisation."""
         ps = [p for p in group["params"] if p.grad is not None]
         if not ps:
             return None
         key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps)
         hit = self._cache.get(gi)
-        if hit is not None and hit[0] == key:
+        if hit is not None and hit["key"] == key:
             return hit
-        dev = ps[0].device
-        chunk = N.lib().md_opt_chunk_elems()
-        tens = np.zeros(len(ps), dtype=_TENSOR_DT)
-        chunks = []
-        for i, p in enumerate(ps):
+        ids = tuple(id(p) for p in ps)
+        if hit is None or hit["ids"] != ids:
+            dev = ps[0].device
+            chunk = N.lib().md_opt_chunk_elems()
+            tens = np.zeros(len(ps), dtype=_TENSOR_DT)
+            chunks = []
+            for i, p in enumerate(ps):
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                    raise RuntimeError("ClipAdamW: parameters must be contiguous CUDA float32 (no CPU fallback)")
+                st = self.state[p]
+                if "exp_avg" not in st:
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                tens[i] = (0, 0, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
+                chunks.extend((i, o) for o in range((p.numel() + chunk - 1) // chunk))
+            ch = np.array(chunks, dtype=_CHUNK_DT)
+            nbytes = tens.nbytes
+            hit = {
+                "ids": ids, "host": tens, "nch": len(chunks),
+                "tens": torch.empty(nbytes, dtype=torch.uint8, device=dev),
+                "chunks": torch.from_numpy(ch.view(np.uint8).copy()).to(dev),
+                "partial": torch.empty(len(chunks) + 2, device=dev, dtype=torch.float32),     # [norm, coef | per-chunk sums]
+                "pinned": [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(self._RING)],
+                "events": [None] * self._RING, "slot": 0,
+            }
+            self._cache[gi] = hit
+        for p in ps:
             g = p.grad
-            if not (p.is_cuda and g.is_cuda and p.dtype == torch.float32 and g.dtype == torch.float32):
-                raise RuntimeError("ClipAdamW: parameters and gradients must be CUDA float32 (no CPU fallback)")
-            if not (p.is_contiguous() and g.is_contiguous()):
-                raise RuntimeError("ClipAdamW: parameters and gradients must be contiguous")
-            st = self.state[p]
-            if "exp_avg" not in st:
-                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-            tens[i] = (p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
-            chunks.extend((i, o) for o in range((p.numel() + chunk - 1) // chunk))
-        ch = np.array(chunks, dtype=_CHUNK_DT)
-        tens_dev = torch.from_numpy(tens.view(np.uint8).copy()).to(dev)
-        ch_dev = torch.from_numpy(ch.view(np.uint8).copy()).to(dev)
-        partial = torch.empty(len(chunks) + 2, device=dev, dtype=torch.float32)       # [norm, coef | per-chunk sums]
-        hit = (key, tens_dev, ch_dev, len(chunks), partial)
-        self._cache[gi] = hit
+            if not (g.is_cuda and g.dtype == torch.float32 and g.is_contiguous()):
+                raise RuntimeError("ClipAdamW: gradients must be contiguous CUDA float32 (no CPU fallback)")
+        tens = hit["host"]
+        tens["p"] = [k[0] for k in key]
+        tens["g"] = [k[1] for k in key]
+        slot = hit["slot"]; hit["slot"] = (slot + 1) % self._RING
+        if hit["events"][slot] is not None:
+            hit["events"][slot].synchronize()             # this staging buffer's previous copy (4 refreshes ago) is done
+        pin = hit["pinned"][slot]
+        pin.numpy()[:] = tens.view(np.uint8)
+        hit["tens"].copy_(pin, non_blocking=True)
+        ev = torch.cuda.Event(); ev.record(); hit["events"][slot] = ev
+        hit["key"] = key
         return hit
 
     # ------------------------------------------------------------------ step
@@ -83,7 +109,8 @@ class ClipAdamW(torch.optim.Optimizer):
         live = [(g, t) for g, t in live if t is not None]
         if max_norm and len(live) > 1:
             raise RuntimeError("ClipAdamW: gradient clipping across several parameter groups is not supported")
-        for group, (_, tens, chunks, nch, partial) in live:
+        for group, tb in live:
+            tens, chunks, nch, partial = tb["tens"], tb["chunks"], tb["nch"], tb["partial"]
             coef = None
             if max_norm:
                 N.check(L.md_opt_grad_norm(C.c_void_p(tens.data_ptr()), C.c_void_p(chunks.data_ptr()), nch, float(max_norm),

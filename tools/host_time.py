@@ -1,29 +1,42 @@
-"""Host-side (launch) time of one bench step vs its device time: tells whether the step is host-bound."""
-import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'disruption-prediciton-based-on-multimodal-deep-learning_amd'))
+"""Is the training step host-bound?  Time for the host to QUEUE n steps vs time for the GPU to finish them:
+    python tools/host_time.py"""
+import sys, os, time; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'disruption-prediciton-based-on-multimodal-deep-learning_amd'))
 import torch
-import bench
 from src.models.R2Plus1D import R2Plus1DClassifier
 from src.loss import FocalLoss
+from src.optim import ClipAdamW
 dev = torch.device('cuda:0')
-torch.manual_seed(0)
-model = R2Plus1DClassifier((3, bench.T, bench.S, bench.S), 2, bench.LAYERS, False, bench.ALPHA).to(dev).train()
-loss_fn = FocalLoss(torch.ones(2), 2.0)
-opt = torch.optim.AdamW(model.parameters(), lr=2e-4, fused=True)
-x, y = bench.synth_batch(dev, 1)
-def seg(name, f, acc):
-    t0 = time.perf_counter(); r = f(); acc[name] = acc.get(name, 0.0) + time.perf_counter() - t0; return r
-for it in range(8):
-    acc = {}
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    seg('zero_grad', lambda: opt.zero_grad(set_to_none=True), acc)
-    logits = seg('forward', lambda: model(x), acc)
-    loss = seg('loss', lambda: loss_fn(logits, y), acc)
-    seg('backward', lambda: loss.backward(), acc)
-    seg('clip', lambda: torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0), acc)
-    seg('adamw', lambda: opt.step(), acc)
-    host = time.perf_counter() - t0
-    torch.cuda.synchronize(); total = time.perf_counter() - t0
-    if it >= 3:
-        print('host %.2f ms, host+device %.2f ms | ' % (host * 1e3, total * 1e3) + ' '.join('%s %.2f' % (k, v * 1e3) for k, v in acc.items()))
+torch.manual_seed(1234)
+model = R2Plus1DClassifier(input_size=(3, 21, 128, 128), num_classes=2, layer_sizes=[1, 2, 2, 1], alpha=0.01).to(dev).train()
+loss_fn = FocalLoss(weight=torch.ones(2), gamma=2.0)
+opt = ClipAdamW(model.parameters(), lr=2e-4)
+x = torch.randn(8, 3, 21, 128, 128, device=dev) * 50; y = torch.tensor([0, 1, 0, 0, 1, 0, 0, 0], device=dev)
+def step():
+    opt.zero_grad(set_to_none=True)
+    loss_fn(model(x), y).backward()
+    opt.step(max_norm=1.0)
+for _ in range(5): step()
+torch.cuda.synchronize()
+n = 20
+t0 = time.perf_counter()
+for _ in range(n): step()
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print(f"host queues a step in {(t1-t0)/n*1e3:.3f} ms; GPU finishes a step in {(t2-t0)/n*1e3:.3f} ms")
+# host cost with an idle GPU (sync after every step): pure launch + python time
+ts = []
+for _ in range(10):
+    torch.cuda.synchronize(); a = time.perf_counter(); step(); ts.append(time.perf_counter() - a)
+print(f"host-only step time (GPU idle at entry): {min(ts)*1e3:.3f} ms")
+# ---- per-phase host time (no device sync inside; GPU drained before each step)
+import collections
+acc = collections.defaultdict(float)
+for _ in range(10):
+    torch.cuda.synchronize()
+    a = time.perf_counter(); opt.zero_grad(set_to_none=True); b = time.perf_counter(); acc['zero_grad'] += b - a
+    out = model(x); c = time.perf_counter(); acc['forward'] += c - b
+    l = loss_fn(out, y); d = time.perf_counter(); acc['loss'] += d - c
+    l.backward(); e = time.perf_counter(); acc['backward'] += e - d
+    opt.step(max_norm=1.0); f = time.perf_counter(); acc['opt.step'] += f - e
+print({k: round(v / 10 * 1e3, 3) for k, v in acc.items()})

@@ -254,7 +254,7 @@ extern "C" int md_plan_use_side_stream(MdPlan* P, int enable) {
 extern "C" int md_plan_profile_enable(MdPlan* P, int enable) {
   if (!P) return MD_ERR_NULL;
   P->prof.on = enable != 0;
-  P->prof.used = 0;
+  if (enable == 1) P->prof.used = 0;        // 0 (off) and 2 (resume) keep what has been recorded: sampling some steps of a run
   return MD_OK;
 }
 // Sum of event-measured durations (ms), launch counts and algorithmic FLOPs per class since the last read

@@ -52,8 +52,9 @@ class TrunkPlan:
         """Backward schedule (md_plan_use_side_stream): concurrent weight gradients (default) or one serial stream."""
         N.check(N.lib().md_plan_use_side_stream(self._h, int(bool(on))), "md_plan_use_side_stream")
 
-    def profile_enable(self, on: bool) -> None:
-        N.check(N.lib().md_plan_profile_enable(self._h, int(on)), "md_plan_profile_enable")
+    def profile_enable(self, on, keep: bool = False) -> None:
+        """HIP events around every conv launch; keep=True resumes without forgetting earlier records (step sampling)."""
+        N.check(N.lib().md_plan_profile_enable(self._h, (2 if keep else 1) if on else 0), "md_plan_profile_enable")
 
     def profile_read(self):
         """[(ms, launches, flops)] for conv forward / data-gradient / weight-gradient since the last read."""

@@ -224,7 +224,9 @@ int md_plan_use_side_stream(MdPlan* p, int32_t enable);
 /* Measurement aid (bench.py roofline leg): bracket every convolution launch of the plan with HIP events on
  * the launch stream.  md_plan_profile_read sums, per kernel class (0 conv forward, 1 conv data-gradient,
  * 2 conv weight-gradient), the measured milliseconds, the launch count and the algorithmic FLOPs
- * (2 * output pixels * Cout * Cin * taps per launch) since the previous read; it waits on the events. */
+ * (2 * output pixels * Cout * Cin * taps per launch) since the previous read; it waits on the events.
+ * enable: 0 = off (records are kept), 1 = on and forget earlier records, 2 = on, keeping earlier records (to sample
+ * some steps of a run: the events cost ~8 % of a step when every launch of every step is bracketed). */
 int md_plan_profile_enable(MdPlan* p, int enable);
 int md_plan_profile_read(MdPlan* p, double* ms, int64_t* launches, double* flops);
 

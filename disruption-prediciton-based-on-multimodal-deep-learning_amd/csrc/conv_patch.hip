@@ -1372,7 +1372,8 @@ static bool wgrad_build(const MdConvDesc* d, WGeom* out, size_t* lds_bytes, int*
   }
   g.N16 = md_round_up(d->Cout, 16);
   const int NT = g.N16 / 16;
-  g.nng = md_cdiv(NT, WNR); g.nrep = md_cdiv(NT, g.nng);
+  static const int wnr = getenv("MD_WGRAD_NR") ? atoi(getenv("MD_WGRAD_NR")) : WNR;     // column tiles per workgroup (<= WNR)
+  g.nng = md_cdiv(NT, wnr < 1 ? 1 : (wnr > WNR ? WNR : wnr)); g.nrep = md_cdiv(NT, g.nng);
   { const int q = md_cdiv(g.nkt, 4); g.ktw = q <= 3 ? 3 : (q == 4 ? 4 : WKT); }     // instantiated: 3, 4 or 5 k-tiles per wave
   g.nkg = md_cdiv(g.nkt, 4 * g.ktw);
   g.NC = 2 * g.nrep;

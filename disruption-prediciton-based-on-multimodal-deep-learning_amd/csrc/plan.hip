@@ -70,7 +70,8 @@ static bool side_stream(MdPlan* P) {
   if (off) return false;
   int lo = 0, hi = 0;
   if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); return false; }
-  if (hipStreamCreateWithPriority(&P->side, hipStreamNonBlocking, lo) != hipSuccess) { (void)hipGetLastError(); return false; }
+  static const int prio_hi = getenv("MD_SIDE_PRIO_HIGH") && atoi(getenv("MD_SIDE_PRIO_HIGH")) == 1;     // experiment
+  if (hipStreamCreateWithPriority(&P->side, hipStreamNonBlocking, prio_hi ? hi : lo) != hipSuccess) { (void)hipGetLastError(); return false; }
   bool ok = true;
   for (auto& e : P->ev_ready) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
   for (auto& e : P->ev_done) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;

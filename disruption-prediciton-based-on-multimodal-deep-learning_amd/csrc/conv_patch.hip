@@ -1067,8 +1067,10 @@ __global__ __launch_bounds__(256) void k_wgrad_patch(
 // ------------------------------------------------------------------------------------------------
 #define WPF_X 7
 #define WPF_Y 5
-template <int KTW, int NREP>
-__global__ __launch_bounds__(256) void k_wgrad_patch_pf(
+// W8: eight waves (512 threads) per box -- wave = (k-tile group wk, column half wn); two waves per SIMD overlap each
+// other's commit (VALU), request and MFMA phases, which one 4-wave workgroup per CU (384-428 VGPRs) cannot.
+template <int KTW, int NREP, bool W8 = false>
+__global__ __launch_bounds__(W8 ? 512 : 256) void k_wgrad_patch_pf(
     WGeom g, const float* __restrict__ src, const float* __restrict__ pscale, const float* __restrict__ pshift,
     float pslope, const float* __restrict__ dy, float* __restrict__ slab) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
@@ -1078,27 +1080,32 @@ __global__ __launch_bounds__(256) void k_wgrad_patch_pf(
   float* sScale = (float*)(sm + g.off_scale);
   float* sShift = sScale + PMAXC;
 
+  constexpr int NT = W8 ? 512 : 256;
+  constexpr int NX = W8 ? 4 : WPF_X, NY = W8 ? 3 : WPF_Y;    // 32-byte items per thread: X patch, dY rows
+  constexpr int NW = W8 ? (NREP + 1) / 2 : NREP;                   // column tiles per wave
   const int t = threadIdx.x;
   const int lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6) & 3;     // k-tile group of this wave
+  const int wn = __builtin_amdgcn_readfirstlane(t >> 8);           // column half (W8)
+  const int j0 = wn ? NREP - NW : 0;                               // first column tile (odd NREP: the halves overlap by one)
   const int li = lane & 15, lg = lane >> 4;
   const int lq = li >> 2, lp = li & 3;
   const int kg = blockIdx.y / g.nng, ng = blockIdx.y - kg * g.nng;
   const int n0 = ng * g.nrep * 16;
   const int kt0 = (kg * 4 + wave) * g.ktw;
   const bool prologue = pscale != nullptr;
-  if (prologue) for (int c = t; c < g.Cpi; c += 256) { const int cs = g.pack2 ? (c & 3) : c; sScale[c] = pscale[cs]; sShift[c] = pshift[cs]; }
+  if (prologue) for (int c = t; c < g.Cpi; c += NT) { const int cs = g.pack2 ? (c & 3) : c; sScale[c] = pscale[cs]; sShift[c] = pshift[cs]; }
   if (t < PM) {
     const int rt = t / g.byx; const int r = t - rt * g.byx;
     const int ry = r / g.bx; const int rx = r - ry * g.bx;
     sRx[t] = (rt < g.bt) ? ((rt * g.st * g.py + ry * g.sh) * g.px + rx * g.sw) * g.ppitch : 0;
   }
 
-  f32x4 acc[KTW][NREP];
+  f32x4 acc[KTW][NW];
 #pragma unroll
   for (int a = 0; a < KTW; ++a)
 #pragma unroll
-    for (int j = 0; j < NREP; ++j) acc[a][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NW; ++j) acc[a][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   int koff[KTW];
 #pragma unroll
   for (int a = 0; a < KTW; ++a) {
@@ -1117,12 +1124,12 @@ __global__ __launch_bounds__(256) void k_wgrad_patch_pf(
   const int totX = g.P * g.C8i, totY = PM * g.NC;
   const int xcv4 = g.Cpi >> 2;
   const int ycv4 = max(0, min(g.NC * 2, (g.Cpo - n0) >> 2));
-  int xloc[WPF_X], xdst[WPF_X];      // packed (ppt | ppy<<6 | ppx<<15 | c8<<24), LDS byte offset (or -1: no item)
-  int yloc[WPF_Y], ydst[WPF_Y];      // packed (rt | ry<<6 | rx<<15 | c<<24)
-  int xrel[WPF_X], yrel[WPF_Y];      // element offset of the item relative to the box origin
+  int xloc[NX], xdst[NX];      // packed (ppt | ppy<<6 | ppx<<15 | c8<<24), LDS byte offset (or -1: no item)
+  int yloc[NY], ydst[NY];      // packed (rt | ry<<6 | rx<<15 | c<<24)
+  int xrel[NX], yrel[NY];      // element offset of the item relative to the box origin
 #pragma unroll
-  for (int u = 0; u < WPF_X; ++u) {
-    const int item = u * 256 + t;
+  for (int u = 0; u < NX; ++u) {
+    const int item = u * NT + t;
     xdst[u] = -1; xloc[u] = 0; xrel[u] = 0;
     if (item < totX) {
       const int pixel = g.magicC8 ? (int)__umulhi((unsigned)item, g.magicC8) : item;
@@ -1135,8 +1142,8 @@ __global__ __launch_bounds__(256) void k_wgrad_patch_pf(
     }
   }
 #pragma unroll
-  for (int u = 0; u < WPF_Y; ++u) {
-    const int item = u * 256 + t;
+  for (int u = 0; u < NY; ++u) {
+    const int item = u * NT + t;
     ydst[u] = -1; yloc[u] = 0; yrel[u] = 0;
     if (item < totY) {
       const int row = g.magicNC ? (int)__umulhi((unsigned)item, g.magicNC) : item;
@@ -1149,7 +1156,7 @@ __global__ __launch_bounds__(256) void k_wgrad_patch_pf(
     }
   }
 
-  float4 xa_[WPF_X], xb_[WPF_X], ya_[WPF_Y], yb_[WPF_Y];
+  float4 xa_[NX], xb_[NX], ya_[NY], yb_[NY];
   int xfl = 0;                // per item 2 bits: bit0 = loaded (inside the tensor), bit1 = upper half is padding
   const __amdgpu_buffer_rsrc_t xrs = make_rsrc(src, g.x_bytes), yrs = make_rsrc(dy, g.y_bytes);
   // Box being requested (scalars): clip index, output-box origin, input-patch origin, element offsets of the origins.
@@ -1188,7 +1195,7 @@ __global__ __launch_bounds__(256) void k_wgrad_patch_pf(
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int u = 0; u < WPF_X; ++u) {
+    for (int u = 0; u < NX; ++u) {
       if (xdst[u] >= 0) {
         float v[8] = {xa_[u].x, xa_[u].y, xa_[u].z, xa_[u].w, xb_[u].x, xb_[u].y, xb_[u].z, xb_[u].w};
         if (prologue && ((xfl >> (2 * u)) & 1)) {
@@ -1205,9 +1212,9 @@ __global__ __launch_bounds__(256) void k_wgrad_patch_pf(
       }
     }
 #pragma unroll
-    for (int u = 0; u < WPF_Y; ++u) {
+    for (int u = 0; u < NY; ++u) {
       if (ydst[u] != -1) {
-        const int item = u * 256 + t;
+        const int item = u * NT + t;
         const int row = g.magicNC ? (int)__umulhi((unsigned)item, g.magicNC) : item;
         const int off = row * g.ypitch + ((yloc[u] >> 24) & 255) * 16;
         const float v[8] = {ya_[u].x, ya_[u].y, ya_[u].z, ya_[u].w, yb_[u].x, yb_[u].y, yb_[u].z, yb_[u].w};
@@ -1230,9 +1237,9 @@ __global__ __launch_bounds__(256) void k_wgrad_patch_pf(
   if (box_beg < box_end) {
     aim(box_beg, true);
 #pragma unroll
-    for (int u = 0; u < WPF_X; ++u) issue_x(u);
+    for (int u = 0; u < NX; ++u) issue_x(u);
 #pragma unroll
-    for (int u = 0; u < WPF_Y; ++u) issue_y(u);
+    for (int u = 0; u < NY; ++u) issue_y(u);
   }
   PH(0);
   for (int box = box_beg; box < box_end; ++box) {
@@ -1249,32 +1256,32 @@ __global__ __launch_bounds__(256) void k_wgrad_patch_pf(
       const int r0 = s * 32 + lg * 4 + lq;
       const int xa = sRx[r0] + lp * 8, xb2 = sRx[r0 + 16] + lp * 8;
       const int ya = r0 * g.ypitch + lp * 8, yb2 = (r0 + 16) * g.ypitch + lp * 8;
-      bf16x8 bh[NREP], bl[NREP];
+      bf16x8 bh[NW], bl[NW];
 #pragma unroll
-      for (int j = 0; j < NREP; ++j) {
-        bh[j] = tr_read2(sY + ya + j * 32, sY + yb2 + j * 32);
-        bl[j] = tr_read2(sY + g.ylo_off + ya + j * 32, sY + g.ylo_off + yb2 + j * 32);
+      for (int j = 0; j < NW; ++j) {
+        bh[j] = tr_read2(sY + ya + (j0 + j) * 32, sY + yb2 + (j0 + j) * 32);
+        bl[j] = tr_read2(sY + g.ylo_off + ya + (j0 + j) * 32, sY + g.ylo_off + yb2 + (j0 + j) * 32);
       }
 #pragma unroll
       for (int a = 0; a < KTW; ++a) {
         {
           const int grp = s * KTW + a;          // 4*KTW >= 12 groups for the 7 + 5 items
-          if (grp < WPF_X) issue_x(grp);
-          else if (grp - WPF_X < WPF_Y) issue_y(grp - WPF_X);
+          if (grp < NX) issue_x(grp);
+          else if (grp - NX < NY) issue_y(grp - NX);
         }
         const bf16x8 ah = tr_read2(sP + xa + koff[a], sP + xb2 + koff[a]);
         const bf16x8 al = tr_read2(sP + g.lo_off + xa + koff[a], sP + g.lo_off + xb2 + koff[a]);
 #pragma unroll
-        for (int j = 0; j < NREP; ++j) {
+        for (int j = 0; j < NW; ++j) {
           acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[a][j], 0, 0, 0);
           acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[a][j], 0, 0, 0);
           acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[a][j], 0, 0, 0);
         }
-        if (s * KTW + a < WPF_X + WPF_Y) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);      // this group's two requests,
-        __builtin_amdgcn_sched_group_barrier(0x008, 3 * NREP, 0);                                 // then its MFMAs
+        if (s * KTW + a < NX + NY) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);      // this group's two requests,
+        __builtin_amdgcn_sched_group_barrier(0x008, 3 * NW, 0);                                 // then its MFMAs
         // (the scheduler fills groups bottom-up and would otherwise sink the requests to the END of the MFMA phase,
         // where their latency is exposed at the next commit)
-        if (s * KTW + a == WPF_X + WPF_Y - 1) __builtin_amdgcn_sched_barrier(0);
+        if (s * KTW + a == NX + NY - 1) __builtin_amdgcn_sched_barrier(0);
       }
     }
     PH(5);
@@ -1290,9 +1297,10 @@ __global__ __launch_bounds__(256) void k_wgrad_patch_pf(
     const int kt = kt0 + a;
     if (kt < g.nkt) {
 #pragma unroll
-      for (int j = 0; j < NREP; ++j) {
-        const int col = n0 + j * 16 + li;
-        if (col < g.N16) {
+      for (int j = 0; j < NW; ++j) {
+        const int col = n0 + (j0 + j) * 16 + li;
+        const bool dup = W8 && (NREP & 1) && wn == 1 && j == 0;      // written by the first column half
+        if (col < g.N16 && !dup) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) out[(size_t)(kt * 16 + lg * 4 + r) * g.N16 + col] = acc[a][j][r];
         }
@@ -1340,7 +1348,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
   }
 }
 
-struct WgradPlan { WGeom g; size_t lds; int nslices; };
+struct WgradPlan { WGeom g; size_t lds; int nslices; bool w8; };
 
 static bool wgrad_build(const MdConvDesc* d, WGeom* out, size_t* lds_bytes, int* nslices) {
   WGeom g;
@@ -1478,12 +1486,16 @@ const WgradPlan* wgrad_lookup(const MdConvDesc* d) {
     // 160: 1097, 192: 1085, 256: 1068 clips/s); with the side stream switched off the kernel takes the whole chip.
     static const int side_off = getenv("MD_WGRAD_STREAM") && atoi(getenv("MD_WGRAD_STREAM")) == 0;
     static const int fill = getenv("MD_WGRAD_FILL") ? atoi(getenv("MD_WGRAD_FILL")) : (side_off ? 256 : 160);
-    int want = md_cdiv(fill * wgrad_wgs_per_cu(g, lds), g.nkg * g.nng);
+    const int occ = wgrad_wgs_per_cu(g, lds);
+    // eight-wave form of the prefetching kernel where only one 4-wave workgroup would fit a CU
+    static const int w8_env = getenv("MD_WGRAD_W8") ? atoi(getenv("MD_WGRAD_W8")) : 1;
+    const bool w8 = w8_env && occ == 1 && wgrad_use_pf(g) && g.nrep >= 2;
+    int want = md_cdiv(fill * occ, g.nkg * g.nng);
     if (want > g.nboxes) want = g.nboxes;
     if (want < 1) want = 1;
     g.boxes_per_wg = md_cdiv(g.nboxes, want);
     ns = md_cdiv(g.nboxes, g.boxes_per_wg);
-    wp = new WgradPlan(); wp->g = g; wp->lds = lds; wp->nslices = ns;
+    wp = new WgradPlan(); wp->g = g; wp->lds = lds; wp->nslices = ns; wp->w8 = w8;
   }
   cache[key] = wp;
   return wp;
@@ -1507,7 +1519,16 @@ int wgrad_patch_launch(const WgradPlan* p, const MdConvDesc* d, const float* src
                               160 * 1024) != hipSuccess) return MD_ERR_LAUNCH;                                          \
       set_ = true;                                                                                                      \
     }                                                                                                                   \
-    if (pf)                                                                                                             \
+    if (pf && p->w8 && NR_ >= 2) {                                                                                      \
+      static bool set8_ = false;                                                                                        \
+      if (!set8_) {                                                                                                     \
+        if (hipFuncSetAttribute((const void*)k_wgrad_patch_pf<KT_, NR_, true>,                                          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)                  \
+          return MD_ERR_LAUNCH;                                                                                         \
+        set8_ = true;                                                                                                   \
+      }                                                                                                                 \
+      MD_KLAUNCH((k_wgrad_patch_pf<KT_, NR_, true>), grid, dim3(512), p->lds, s, g, src, ps, psh, slope, dy, slab);     \
+    } else if (pf)                                                                                                      \
       MD_KLAUNCH((k_wgrad_patch_pf<KT_, NR_>), grid, dim3(256), p->lds, s, g, src, ps, psh, slope, dy, slab);   \
     else                                                                                                                \
       MD_KLAUNCH((k_wgrad_patch<KT_, NR_>), grid, dim3(256), p->lds, s, g, src, ps, psh, slope, dy, slab, dbg); \

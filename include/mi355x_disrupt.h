@@ -216,7 +216,7 @@ int md_plan_backward_range(MdPlan* p, const float* dfeat, const float* const* w,
                            float* const* dw, float* const* dgamma, float* const* dbeta,
                            void* workspace, int32_t stage_hi, int32_t stage_lo, void* stream);
 int32_t md_plan_feat_dim(const MdPlan* p);
-/* Backward schedule: with enable != 0 (default) the weight gradient of a unit is queued on an internal low-priority
+/* Backward schedule: with enable != 0 (default) the weight gradient of a unit is queued on an internal
  * stream as soon as the unit's output gradient is final, concurrently with the BatchNorm-backward / data-gradient chain
  * on the caller's stream; every md_plan_backward_range call joins the two before returning to the caller's stream
  * order.  enable == 0 queues everything on the caller's stream.  Same kernels, bit-identical results. */

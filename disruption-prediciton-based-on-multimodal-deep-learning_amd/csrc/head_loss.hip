@@ -12,16 +12,32 @@ __global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ feat
                                                   const float* __restrict__ w1, const float* __restrict__ b1, float alpha,
                                                   float eps, float momentum, int training, float* __restrict__ rmean,
                                                   float* __restrict__ rvar, float* __restrict__ logits,
-                                                  float* __restrict__ save) {
+                                                  float* __restrict__ save, int stage_w) {
   extern __shared__ float sm[];
   float* h0 = sm;            // [B][Hd]
   float* he = h0 + B * Hd;   // [B][Hd]
   const int t = threadIdx.x, nt = blockDim.x;
-  for (int e = t; e < B * Hd; e += nt) {
-    const int b = e / Hd, j = e - b * Hd;
-    float a = b0[j];
-    for (int d = 0; d < D; ++d) a = fmaf(feat[b * D + d], w0[j * D + d], a);
-    h0[e] = a;
+  if (stage_w) {
+    // w0 and feat staged with coalesced loads (row pitch D+1: the per-thread rows below then fall on different banks);
+    // the dot products keep their serial order, so the result is bit-identical to reading global memory directly
+    float* w0s = he + B * Hd;          // [Hd][D+1]
+    float* fs = w0s + Hd * (D + 1);    // [B][D]
+    for (int e = t; e < Hd * D; e += nt) { const int j = e / D, d = e - j * D; w0s[j * (D + 1) + d] = w0[e]; }
+    for (int e = t; e < B * D; e += nt) fs[e] = feat[e];
+    __syncthreads();
+    for (int e = t; e < B * Hd; e += nt) {
+      const int b = e / Hd, j = e - b * Hd;
+      float a = b0[j];
+      for (int d = 0; d < D; ++d) a = fmaf(fs[b * D + d], w0s[j * (D + 1) + d], a);
+      h0[e] = a;
+    }
+  } else {
+    for (int e = t; e < B * Hd; e += nt) {
+      const int b = e / Hd, j = e - b * Hd;
+      float a = b0[j];
+      for (int d = 0; d < D; ++d) a = fmaf(feat[b * D + d], w0[j * D + d], a);
+      h0[e] = a;
+    }
   }
   __syncthreads();
   float* xhat = save; float* hn = save + B * Hd; float* hes = save + 2 * B * Hd; float* istd = save + 3 * B * Hd;
@@ -111,10 +127,13 @@ extern "C" int md_head_fwd(const float* feat, int32_t B, int32_t D, int32_t Hd, 
   if (!feat || !w0 || !b0 || !gamma || !beta || !w1 || !b1 || !logits || !save) return MD_ERR_NULL;
   if (!training && (!running_mean || !running_var)) return MD_ERR_NULL;
   if (B <= 0 || D <= 0 || Hd <= 0 || K <= 0) return MD_ERR_BAD_SHAPE;
-  const size_t lds = (size_t)2 * B * Hd * 4;
+  size_t lds = (size_t)2 * B * Hd * 4;
   if (lds > 60000) return MD_ERR_UNSUPPORTED;
+  const size_t lds_w = lds + ((size_t)Hd * (D + 1) + (size_t)B * D) * 4;
+  const int stage_w = lds_w <= 60000;
+  if (stage_w) lds = lds_w;
   MD_KLAUNCH(k_head_fwd, dim3(1), dim3(256), lds, (hipStream_t)stream, feat, B, D, Hd, K, w0, b0, gamma, beta, w1,
-                     b1, alpha, eps, momentum, training, running_mean, running_var, logits, save);
+                     b1, alpha, eps, momentum, training, running_mean, running_var, logits, save, stage_w);
   MD_CHECK_LAUNCH();
   return MD_OK;
 }

@@ -47,7 +47,7 @@ struct MdPlan {
   std::vector<Unit> units;
   std::vector<Block> blocks;
   std::vector<ZT> z;
-  size_t part_off, coef_off, slab_off, g_off[4], gmax, total_floats;
+  size_t part_off, part2_off, coef_off, slab_off, g_off[4], gmax, total_floats;
   size_t part_floats;
   int feat_dim;
   int bwd_p;   // gradient buffer currently holding dZ
@@ -184,6 +184,13 @@ extern "C" int md_plan_create(int32_t B, int32_t T, int32_t H, int32_t W, const 
   }
   P->part_floats = pmax;
   P->part_off = take(pmax);
+  {   // statistics partials of the skip-path units (they run on the side stream next to the main path of their block)
+    size_t p2 = 0;
+    for (const Block& b : P->blocks)
+      for (int ui : {b.dss, b.dst})
+        if (ui >= 0) { const Unit& u = P->units[ui]; const size_t n = (size_t)md_conv_fwd_stat_blocks(&u.d) * 2 * u.Cp; if (n > p2) p2 = n; }
+    P->part2_off = take(p2 ? p2 : 4);
+  }
   size_t smax = 0;
   for (auto& u : P->units) { const size_t n = md_conv_wgrad_workspace_floats(&u.d); if (n > smax) smax = n; }
   P->slab_off = take(smax);
@@ -316,16 +323,48 @@ extern "C" int md_plan_forward(MdPlan* P, const float* x, const float* const* w,
     }
   }
   size_t next_block = 0;
+  // conv + BatchNorm statistics of one unit in training mode, on stream `s` with partial-sum scratch `part`
+  auto train_unit = [&](size_t i, float* part, void* s) -> int {
+    const Unit& u = P->units[i];
+    MdActView in = unit_in_view(P, ws, (int)i);
+    float* st = ws + u.stat_off;
+    { ProfScope ps(P, KC_FWD, unit_flops(u), s);
+      RC(md_conv_fwd(&u.d, &in, ws + u.wf_off, ws + u.raw_off, part, s)); }
+    return md_bn_finalize(part, md_conv_fwd_stat_blocks(&u.d), u.d.Cout, u.rows, gamma[i], beta[i], 1e-5f, 0.1f,
+                          rmean ? rmean[i] : nullptr, rvar ? rvar[i] : nullptr, st, st + u.Cp, st + 2 * u.Cp, st + 3 * u.Cp, s);
+  };
+  bool skip_on_side = false;       // the current block's skip path (dss, dst) has been queued on the side stream
   for (size_t i = 0; i < P->units.size(); ++i) {
     const Unit& u = P->units[i];
     MdActView in = unit_in_view(P, ws, (int)i);
     float* st = ws + u.stat_off;
+    if (training && next_block < P->blocks.size()) {
+      const Block& b = P->blocks[next_block];
+      if ((int)i == b.c1s && b.dst >= 0 && side_stream(P)) {
+        // downsampling block: its 1x1x1 skip convolutions depend only on the block input -- run them on the side stream
+        // while the four main-path units run here; the residual close below waits for them
+        hipEvent_t ready = P->ev_ready[P->ready_ix]; P->ready_ix ^= 1;
+        if (hipEventRecord(ready, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(P->side, ready, 0) != hipSuccess)
+          return MD_ERR_LAUNCH;
+        RC(train_unit((size_t)b.dss, ws + P->part2_off, P->side));
+        RC(train_unit((size_t)b.dst, ws + P->part2_off, P->side));
+        P->side_used = true; skip_on_side = true;
+      }
+      if (skip_on_side && ((int)i == b.dss || (int)i == b.dst)) {
+        if ((int)i == b.dst) {
+          RC(join_side(P, stream));
+          skip_on_side = false;
+          MdActView mainv = unit_out_view(P, ws, b.c2t);
+          MdActView skipv = unit_out_view(P, ws, b.dst);
+          const Unit& t2 = P->units[b.c2t];
+          RC(md_residual_fwd(&skipv, &mainv, P->alpha, t2.rows, t2.d.Cout, ws + P->z[b.out_z].off, stream));
+          ++next_block;
+        }
+        continue;
+      }
+    }
     if (training) {
-      { ProfScope ps(P, KC_FWD, unit_flops(u), stream);
-        RC(md_conv_fwd(&u.d, &in, ws + u.wf_off, ws + u.raw_off, ws + P->part_off, stream)); }
-      RC(md_bn_finalize(ws + P->part_off, md_conv_fwd_stat_blocks(&u.d), u.d.Cout, u.rows, gamma[i], beta[i], 1e-5f, 0.1f,
-                        rmean ? rmean[i] : nullptr, rvar ? rvar[i] : nullptr, st, st + u.Cp, st + 2 * u.Cp, st + 3 * u.Cp,
-                        stream));
+      RC(train_unit(i, ws + P->part_off, stream));
     } else {
       RC(md_conv_fwd(&u.d, &in, ws + u.wf_off, ws + u.raw_off, nullptr, stream));
       RC(md_bn_eval_params(u.d.Cout, gamma[i], beta[i], rmean[i], rvar[i], 1e-5f, st, st + u.Cp, st + 2 * u.Cp, st + 3 * u.Cp,

@@ -79,8 +79,8 @@ def test_fullsize_forward_backward(reference, exact):
 
 
 def test_side_stream_schedule_is_bit_identical_to_serial():
-    """Backward with weight gradients on the side stream (default) vs everything on one stream: same kernels, so every
-    gradient must be bit-identical -- a gradient buffer overwritten before its weight gradient has read it (the hazard
+    """Side-stream schedule (forward: skip-path convolutions of the downsampling blocks; backward: weight gradients;
+    default) vs everything on one stream: same kernels, so every gradient must be bit-identical -- a gradient buffer overwritten before its weight gradient has read it (the hazard
     the events guard against) would show up here.  Three repetitions per schedule, BASELINE shape, B=8."""
     model = R2Plus1DClassifier(input_size=(3, T, S, S), num_classes=2, layer_sizes=LS, alpha=ALPHA)
     params, bufs = orc.synth_state(LS, SEED, ALPHA)
@@ -90,13 +90,16 @@ def test_side_stream_schedule_is_bit_identical_to_serial():
     loss_fn = FocalLoss(weight=torch.ones(2), gamma=2.0)
     x = orc.synth_clip(8, T, S, SEED + 1).to(DEV); y = orc.synth_labels(8, SEED + 1).to(DEV)
 
+    with torch.no_grad():
+        model(x)                                  # creates the plan for this shape
+
     def grads(side):
         out = []
         for _ in range(3):
             model.zero_grad(set_to_none=True)
-            logits = model(x)
             for plan in model.res2plus1d._plans.values():
-                plan.use_side_stream(side)
+                plan.use_side_stream(side)        # forward (skip-path convolutions) and backward (weight gradients)
+            logits = model(x)
             loss_fn(logits, y).backward()
             torch.cuda.synchronize()
             out.append([p.grad.detach().clone() for p in model.parameters()])

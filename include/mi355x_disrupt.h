@@ -170,6 +170,16 @@ int md_softmax_loss(int32_t kind, const float* logits, const int64_t* target, in
                     float* loss, float* dlogits, int64_t* pred, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Elementwise pieces of the other encoders (next rows of the scope table).
+ * ---------------------------------------------------------------------------------------------- */
+/* SwishEfficient (src/models/resnet.py:70-81): y = x * sigmoid(x); dx = dy * s * (1 + x * (1 - s)), s = sigmoid(x). */
+int md_swish_fwd(const float* x, int64_t n, float* y, void* stream);
+int md_swish_bwd(const float* x, const float* dy, int64_t n, float* dx, void* stream);
+/* NoiseLayer, training branch (src/models/NoiseLayer.py:12-14): out = x + (mean + noise * std); `noise` holds the
+ * standard-normal draws (the reference draws them with the CPU generator; the caller keeps that choice). */
+int md_add_noise(const float* x, const float* noise, float mean, float std, int64_t n, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Optimizer step: torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm) + torch.optim.AdamW.step()
  * (src/train.py:64-66, train_vision_network.py:277-278) over all parameter tensors in two launches.
  * `tensors` is a device array of MdOptTensor, `chunks` a device array of MdOptChunk covering every tensor in pieces

@@ -219,6 +219,31 @@ def step_fixture():
     print("step", tl, ta, tf, np.stack(preds))
 
 
+def elementwise_fixture():
+    """SwishEfficient (resnet.py:70-81) forward/backward and NoiseLayer (NoiseLayer.py:5-16) outputs of the reference."""
+    from src.models.resnet import SwishEfficient
+    from src.models.NoiseLayer import NoiseLayer
+    rng = np.random.default_rng(2024)
+    x = np.concatenate([rng.standard_normal(4093).astype(np.float32) * 3.0,
+                        np.array([0.0, -0.0, 1e-8, -1e-8, 20.0, -20.0, 88.0, -88.0, 100.0, -100.0], dtype=np.float32)])
+    dy = rng.standard_normal(x.shape[0]).astype(np.float32)
+    xt = torch.from_numpy(x).requires_grad_(True)
+    y = SwishEfficient.apply(xt)
+    y.backward(torch.from_numpy(dy))
+    out = {"swish_x": x, "swish_dy": dy, "swish_y": y.detach().numpy(), "swish_dx": xt.grad.numpy()}
+    xn = rng.standard_normal((6, 21, 14)).astype(np.float32)
+    layer = NoiseLayer(mean=0.05, std=1e-2)
+    layer.train()
+    torch.manual_seed(777)
+    out["noise_x"] = xn
+    out["noise_seed"] = np.int64(777); out["noise_mean"] = np.float32(0.05); out["noise_std"] = np.float32(1e-2)
+    out["noise_train"] = layer(torch.from_numpy(xn)).numpy()
+    layer.eval()
+    out["noise_eval"] = layer(torch.from_numpy(xn)).numpy()
+    np.savez_compressed(os.path.join(HERE, "elementwise.npz"), **out)
+    print("elementwise", float(np.abs(out["swish_y"]).max()), float(np.abs(out["noise_train"] - xn).mean()))
+
+
 if __name__ == "__main__":
     # Several seeds per configuration: LeakyReLU(0.01) makes the gradient discontinuous where a
     # pre-activation crosses zero, so two correct fp32 implementations can disagree by >1e-3 on a whole
@@ -233,3 +258,4 @@ if __name__ == "__main__":
     loss_fixture()
     drw_fixture()
     step_fixture()
+    elementwise_fixture()

@@ -61,6 +61,7 @@ struct MdPlan {
   int ready_ix = 0;
   bool side_used = false;     // work was queued on the side stream since the last join
   int side_state = 0;         // 0 not tried, 1 available, -1 unavailable (then everything stays on the caller's stream)
+  bool defer_join = false;    // md_plan_backward_range leaves the join to the caller (md_plan_join)
 };
 
 static bool side_stream(MdPlan* P) {
@@ -260,6 +261,18 @@ extern "C" int md_plan_use_side_stream(MdPlan* P, int enable) {
   }
   return MD_OK;
 }
+
+// Data-parallel training reduces the weight gradients of a stage as soon as they exist.  With the join deferred,
+// md_plan_backward_range returns without making the caller's stream wait for the side stream; the caller queues the
+// consumer of those gradients behind md_plan_side_stream() instead (the collective then waits for the weight gradients,
+// the backward chain does not), and calls md_plan_join once at the end.
+extern "C" int md_plan_defer_join(MdPlan* P, int defer) {
+  if (!P) return MD_ERR_NULL;
+  P->defer_join = defer != 0;
+  return MD_OK;
+}
+extern "C" void* md_plan_side_stream(MdPlan* P) { return (P && side_stream(P)) ? (void*)P->side : nullptr; }
+extern "C" int md_plan_join(MdPlan* P, void* stream) { return P ? join_side(P, stream) : MD_ERR_NULL; }
 
 extern "C" int md_plan_profile_enable(MdPlan* P, int enable) {
   if (!P) return MD_ERR_NULL;
@@ -484,6 +497,7 @@ extern "C" int md_plan_backward_range(MdPlan* P, const float* dfeat, const float
     RC(unit_backward(P, ws, 1, p, q, 0, false, w, dw, dgamma, dbeta, stream));
     RC(unit_backward(P, ws, 0, q, -1, 0, false, w, dw, dgamma, dbeta, stream));
   }
+  if (P->defer_join) return MD_OK;    // the caller orders its consumers itself (md_plan_side_stream / md_plan_join)
   return join_side(P, stream);        // the weight gradients of this range are ordered before whatever follows
 }
 

@@ -74,6 +74,9 @@ SIGNATURES = {
     "md_plan_profile_enable": (C.c_int, [_P, C.c_int]),
     "md_plan_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "md_plan_use_side_stream": (C.c_int, [_P, _I32]),
+    "md_plan_defer_join": (C.c_int, [_P, _I32]),
+    "md_plan_side_stream": (C.c_void_p, [_P]),
+    "md_plan_join": (C.c_int, [_P, _P]),
     "md_swish_fwd": (C.c_int, [_P, C.c_int64, _P, _P]),
     "md_swish_bwd": (C.c_int, [_P, _P, C.c_int64, _P, _P]),
     "md_add_noise": (C.c_int, [_P, _P, _F, _F, C.c_int64, _P, _P]),

@@ -52,6 +52,17 @@ class TrunkPlan:
         """Backward schedule (md_plan_use_side_stream): concurrent weight gradients (default) or one serial stream."""
         N.check(N.lib().md_plan_use_side_stream(self._h, int(bool(on))), "md_plan_use_side_stream")
 
+    def side_stream(self):
+        """The plan's side stream as a torch stream (None when there is none): see md_plan_defer_join."""
+        h = N.lib().md_plan_side_stream(self._h)
+        return torch.cuda.ExternalStream(h) if h else None
+
+    def defer_join(self, on: bool) -> None:
+        N.check(N.lib().md_plan_defer_join(self._h, int(bool(on))), "md_plan_defer_join")
+
+    def join(self) -> None:
+        N.check(N.lib().md_plan_join(self._h, _stream()), "md_plan_join")
+
     def profile_enable(self, on, keep: bool = False) -> None:
         """HIP events around every conv launch; keep=True resumes without forgetting earlier records (step sampling)."""
         N.check(N.lib().md_plan_profile_enable(self._h, (2 if keep else 1) if on else 0), "md_plan_profile_enable")
@@ -124,8 +135,18 @@ class TrunkFunction(torch.autograd.Function):
         if ctx.seg_hook is None:
             plan.backward_range(dfeat, ctx.ws, weights, gammas, dws, dgs, dbs, 4, 0)
         else:
-            for st in (4, 3, 2, 1, 0):
-                plan.backward_range(dfeat, ctx.ws, weights, gammas, dws, dgs, dbs, st, st)
-                ctx.seg_hook(st, flat, grads)
+            # stage-wise gradient exchange: a stage's weight gradients are produced on the plan's side stream; the hook
+            # queues their all-reduce behind THAT stream, so the collective waits for them and the backward chain on the
+            # current stream does not.  One join at the end, before the BatchNorm gradients / the handles are consumed.
+            side = plan.side_stream()
+            plan.defer_join(side is not None)
+            try:
+                for st in (4, 3, 2, 1, 0):
+                    plan.backward_range(dfeat, ctx.ws, weights, gammas, dws, dgs, dbs, st, st)
+                    if st == 0:
+                        plan.join()
+                    ctx.seg_hook(st, flat, grads, side if st > 0 else None)
+            finally:
+                plan.defer_join(False)
         ctx.ws = None
         return (None, None, None, None, None, None) + tuple(grads)

@@ -113,11 +113,17 @@ class GradAllReducer:
         self._stage_slices = sl
 
     # -- called from TrunkFunction.backward after the backward of stage `st` (4 .. 0); st == -1: drain
-    def _segment_hook(self, st: int, flat: torch.Tensor, grads) -> None:
+    def _segment_hook(self, st: int, flat: torch.Tensor, grads, stream=None) -> None:
+        """`stream`: the stream that produces this stage's weight gradients when it is not the current one (the plan's
+        side stream); the all-reduce is queued behind it."""
         if self._stage_slices is None:
             self._build_stage_slices(grads)
         a, b = self._stage_slices[st]
-        self.pending.append(self._avg(flat[a:b], async_op=True))
+        if stream is not None:
+            with torch.cuda.stream(stream):
+                self.pending.append(self._avg(flat[a:b], async_op=True))
+        else:
+            self.pending.append(self._avg(flat[a:b], async_op=True))
         if st == 0:
             self.pending.append(self._avg(flat[self._w_end:], async_op=True))   # all gammas and betas
             for h in self.pending:

@@ -231,6 +231,14 @@ int32_t md_plan_feat_dim(const MdPlan* p);
  * on the caller's stream; every md_plan_backward_range call joins the two before returning to the caller's stream
  * order.  enable == 0 queues everything on the caller's stream.  Same kernels, bit-identical results. */
 int md_plan_use_side_stream(MdPlan* p, int32_t enable);
+/* Data-parallel use: md_plan_defer_join(p, 1) makes md_plan_backward_range return WITHOUT ordering the caller's stream
+ * after the side stream.  The caller then queues the consumer of a stage's weight gradients (the all-reduce) behind
+ * md_plan_side_stream(p) (NULL when there is no side stream: nothing to wait for), so that the collective waits for the
+ * weight gradients while the backward chain keeps running, and calls md_plan_join(p, stream) before it reads any
+ * gradient on its own stream.  BatchNorm gradients (dgamma, dbeta) are always produced on the caller's stream. */
+int md_plan_defer_join(MdPlan* p, int32_t defer);
+void* md_plan_side_stream(MdPlan* p);
+int md_plan_join(MdPlan* p, void* stream);
 /* Measurement aid (bench.py roofline leg): bracket every convolution launch of the plan with HIP events on
  * the launch stream.  md_plan_profile_read sums, per kernel class (0 conv forward, 1 conv data-gradient,
  * 2 conv weight-gradient), the measured milliseconds, the launch count and the algorithmic FLOPs

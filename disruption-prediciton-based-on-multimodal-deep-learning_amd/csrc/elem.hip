@@ -58,3 +58,169 @@ extern "C" int md_add_noise(const float* x, const float* noise, float mean, floa
   MD_CHECK_LAUNCH();
   return MD_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Squeeze-and-excitation gate + Swish of Bottleneck3D (src/models/resnet.py:182-190) and its residual close (:196-198),
+// on the (N,C,T,H,W) tensors that cross the module boundary (one contiguous row of thw values per (n,c)).
+//   pool[n,c] = mean_thw a;  h = relu(W1 pool + b1);  gate = sigmoid(W2 h + b2);  out = swish(a * gate)
+// Backward: q = a*gate, dq = dout * swish'(q);  da = dq*gate + dpool/thw;  dgate[n,c] = sum_thw dq*a, then through the two
+// tiny fully connected layers.  All reductions are fixed-order trees (bitwise reproducible).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum256(float v, float* red) {      // red: 4 floats of shared memory
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// MODE 0: out[row] = mean(a[row][:]);  MODE 1: out[row] = sum_thw dout * swish'(a*g) * a   (g = gate[row])
+template <int MODE>
+__global__ __launch_bounds__(256) void k_row_reduce(const float* __restrict__ a, const float* __restrict__ gate,
+                                                    const float* __restrict__ dout, int64_t thw, float* __restrict__ out) {
+  __shared__ float red[4];
+  const int64_t row = blockIdx.x;
+  const float* ar = a + row * thw;
+  const float g = MODE == 1 ? gate[row] : 0.f;
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < thw; i += 256) {
+    if (MODE == 0) s += ar[i];
+    else {
+      const float x = ar[i], q = x * g, sg = sigmoidf_(q);
+      s += dout[row * thw + i] * (sg * (1.f + q * (1.f - sg))) * x;
+    }
+  }
+  const float t = block_sum256(s, red);
+  if (threadIdx.x == 0) out[row] = MODE == 0 ? t / (float)thw : t;
+}
+
+// gate forward: one workgroup.  hidden[N][Wd] (post-ReLU) is kept for the backward.
+__global__ __launch_bounds__(256) void k_se_gate_fwd(const float* __restrict__ pool, const float* __restrict__ w1,
+                                                     const float* __restrict__ b1, const float* __restrict__ w2,
+                                                     const float* __restrict__ b2, int N, int Cc, int Wd,
+                                                     float* __restrict__ hidden, float* __restrict__ gate) {
+  for (int e = threadIdx.x; e < N * Wd; e += 256) {
+    const int n = e / Wd, j = e - n * Wd;
+    float acc = b1[j];
+    for (int c = 0; c < Cc; ++c) acc = fmaf(w1[j * Cc + c], pool[n * Cc + c], acc);
+    hidden[e] = acc > 0.f ? acc : 0.f;
+  }
+  __syncthreads();      // (single workgroup: the hidden values were written by this workgroup's threads)
+  __threadfence_block();
+  for (int e = threadIdx.x; e < N * Cc; e += 256) {
+    const int n = e / Cc, c = e - n * Cc;
+    float acc = b2[c];
+    for (int j = 0; j < Wd; ++j) acc = fmaf(w2[c * Wd + j], hidden[n * Wd + j], acc);
+    gate[e] = sigmoidf_(acc);
+  }
+}
+
+// gate backward: one workgroup.  dgate[N][C] -> dpool[N][C], dw1[Wd][C], db1[Wd], dw2[C][Wd], db2[C]; scratch dz2[N][C], dh[N][Wd].
+__global__ __launch_bounds__(256) void k_se_gate_bwd(const float* __restrict__ dgate, const float* __restrict__ gate,
+                                                     const float* __restrict__ hidden, const float* __restrict__ pool,
+                                                     const float* __restrict__ w1, const float* __restrict__ w2, int N,
+                                                     int Cc, int Wd, float* __restrict__ dz2, float* __restrict__ dh,
+                                                     float* __restrict__ dpool, float* __restrict__ dw1,
+                                                     float* __restrict__ db1, float* __restrict__ dw2,
+                                                     float* __restrict__ db2) {
+  const int t = threadIdx.x;
+  for (int e = t; e < N * Cc; e += 256) { const float s = gate[e]; dz2[e] = dgate[e] * s * (1.f - s); }
+  __syncthreads(); __threadfence_block();
+  for (int e = t; e < Cc * Wd; e += 256) {
+    const int c = e / Wd, j = e - c * Wd;
+    float acc = 0.f; for (int n = 0; n < N; ++n) acc = fmaf(dz2[n * Cc + c], hidden[n * Wd + j], acc);
+    dw2[e] = acc;
+  }
+  for (int c = t; c < Cc; c += 256) { float acc = 0.f; for (int n = 0; n < N; ++n) acc += dz2[n * Cc + c]; db2[c] = acc; }
+  for (int e = t; e < N * Wd; e += 256) {
+    const int n = e / Wd, j = e - n * Wd;
+    float acc = 0.f; for (int c = 0; c < Cc; ++c) acc = fmaf(dz2[n * Cc + c], w2[c * Wd + j], acc);
+    dh[e] = hidden[e] > 0.f ? acc : 0.f;
+  }
+  __syncthreads(); __threadfence_block();
+  for (int e = t; e < Wd * Cc; e += 256) {
+    const int j = e / Cc, c = e - j * Cc;
+    float acc = 0.f; for (int n = 0; n < N; ++n) acc = fmaf(dh[n * Wd + j], pool[n * Cc + c], acc);
+    dw1[e] = acc;
+  }
+  for (int j = t; j < Wd; j += 256) { float acc = 0.f; for (int n = 0; n < N; ++n) acc += dh[n * Wd + j]; db1[j] = acc; }
+  for (int e = t; e < N * Cc; e += 256) {
+    const int n = e / Cc, c = e - n * Cc;
+    float acc = 0.f; for (int j = 0; j < Wd; ++j) acc = fmaf(dh[n * Wd + j], w1[j * Cc + c], acc);
+    dpool[e] = acc;
+  }
+}
+
+// MODE 0: out = swish(a*g);  MODE 1: da = dout*swish'(a*g)*g + dpool/thw;  MODE 2: out = relu(a+b);  MODE 3: dx = dout*(out>0)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_row_elem(const float* __restrict__ a, const float* __restrict__ b,
+                                                  const float* __restrict__ rowv, const float* __restrict__ rowv2,
+                                                  int64_t thw, int64_t n, float* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    float r;
+    if (MODE == 0) { const float q = a[i] * rowv[i / thw]; r = q * sigmoidf_(q); }
+    else if (MODE == 1) {
+      const int64_t row = i / thw; const float g = rowv[row], q = a[i] * g, sg = sigmoidf_(q);
+      r = b[i] * (sg * (1.f + q * (1.f - sg))) * g + rowv2[row] / (float)thw;
+    }
+    else if (MODE == 2) { const float s = a[i] + b[i]; r = s > 0.f ? s : 0.f; }
+    else r = a[i] > 0.f ? b[i] : 0.f;
+    out[i] = r;
+  }
+}
+
+extern "C" int md_se_swish_fwd(const float* a, int32_t N, int32_t Cc, int64_t thw, int32_t Wd, const float* w1, const float* b1,
+                               const float* w2, const float* b2, float* pool, float* hidden, float* gate, float* out,
+                               void* stream) {
+  if (!a || !w1 || !b1 || !w2 || !b2 || !pool || !hidden || !gate || !out) return MD_ERR_NULL;
+  if (N <= 0 || Cc <= 0 || thw <= 0 || Wd <= 0) return MD_ERR_BAD_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n = (int64_t)N * Cc * thw;
+  MD_KLAUNCH(k_row_reduce<0>, dim3(N * Cc), dim3(256), 0, s, a, (const float*)nullptr, (const float*)nullptr, thw, pool);
+  MD_CHECK_LAUNCH();
+  MD_KLAUNCH(k_se_gate_fwd, dim3(1), dim3(256), 0, s, (const float*)pool, w1, b1, w2, b2, N, Cc, Wd, hidden, gate);
+  MD_CHECK_LAUNCH();
+  MD_KLAUNCH(k_row_elem<0>, dim3(elem_blocks(n)), dim3(256), 0, s, a, (const float*)nullptr, (const float*)gate,
+             (const float*)nullptr, thw, n, out);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+// scratch: 3*N*C + N*Wd floats
+extern "C" int md_se_swish_bwd(const float* a, const float* dout, int32_t N, int32_t Cc, int64_t thw, int32_t Wd,
+                               const float* w1, const float* w2, const float* pool, const float* hidden, const float* gate,
+                               float* da, float* dw1, float* db1, float* dw2, float* db2, float* scratch, void* stream) {
+  if (!a || !dout || !w1 || !w2 || !pool || !hidden || !gate || !da || !dw1 || !db1 || !dw2 || !db2 || !scratch)
+    return MD_ERR_NULL;
+  if (N <= 0 || Cc <= 0 || thw <= 0 || Wd <= 0) return MD_ERR_BAD_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n = (int64_t)N * Cc * thw;
+  float* dgate = scratch; float* dz2 = scratch + (size_t)N * Cc; float* dpool = dz2 + (size_t)N * Cc; float* dh = dpool + (size_t)N * Cc;
+  MD_KLAUNCH(k_row_reduce<1>, dim3(N * Cc), dim3(256), 0, s, a, gate, dout, thw, dgate);
+  MD_CHECK_LAUNCH();
+  MD_KLAUNCH(k_se_gate_bwd, dim3(1), dim3(256), 0, s, (const float*)dgate, gate, hidden, pool, w1, w2, N, Cc, Wd, dz2, dh,
+             dpool, dw1, db1, dw2, db2);
+  MD_CHECK_LAUNCH();
+  MD_KLAUNCH(k_row_elem<1>, dim3(elem_blocks(n)), dim3(256), 0, s, a, dout, gate, (const float*)dpool, thw, n, da);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+extern "C" int md_add_relu_fwd(const float* a, const float* b, int64_t n, float* out, void* stream) {
+  if (!a || !b || !out) return MD_ERR_NULL;
+  if (n <= 0) return MD_ERR_BAD_SHAPE;
+  MD_KLAUNCH(k_row_elem<2>, dim3(elem_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, (const float*)nullptr,
+             (const float*)nullptr, (int64_t)1, n, out);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+extern "C" int md_add_relu_bwd(const float* out, const float* dout, int64_t n, float* dx, void* stream) {
+  if (!out || !dout || !dx) return MD_ERR_NULL;
+  if (n <= 0) return MD_ERR_BAD_SHAPE;
+  MD_KLAUNCH(k_row_elem<3>, dim3(elem_blocks(n)), dim3(256), 0, (hipStream_t)stream, out, dout, (const float*)nullptr,
+             (const float*)nullptr, (int64_t)1, n, dx);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}

@@ -1,9 +1,9 @@
 """MI355X-native pieces of the reference's ``src/models/resnet.py``.
 
-Built here: ``SwishEfficient`` / ``Swish`` (resnet.py:63-81) on ``md_swish_fwd`` / ``md_swish_bwd``.
-Everything else of that module (BasicBlock3D, Bottleneck3D, ResNet3D, SubBatchNorm3d, ...) is not rebuilt yet
-(SURVEY section 8a rows a6-a7).  When ``MD_REFERENCE_SRC`` points at the reference's ``src`` directory those names are
-loaded from the reference file and re-exported with ITS ``Swish`` / ``SwishEfficient`` replaced by the ones below, so
+Built here: ``SwishEfficient`` / ``Swish`` (resnet.py:63-81) on ``md_swish_fwd`` / ``md_swish_bwd`` and ``Bottleneck3D``
+(resnet.py:121-200).  The rest of that module (BasicBlock3D, ResNet3D, SubBatchNorm3d,
+Bottleneck2DPlus1D, ...) is not rebuilt yet (row a7).  When ``MD_REFERENCE_SRC`` points at the reference's ``src`` directory those names are
+loaded from the reference file and re-exported with ITS ``Swish`` / ``SwishEfficient`` / ``Bottleneck3D`` replaced by the ones below, so
 ``from src.models.resnet import *`` (slowfast.py:5) keeps working and the reference's SlowFast runs its Swish on the
 gfx950 kernel.  Without it this module exports the two native names only.
 """
@@ -15,6 +15,7 @@ import torch.nn as nn
 
 from .. import _native as N
 from .. import ops
+from ._unit import conv_bn_leaky
 
 
 class SwishEfficient(torch.autograd.Function):
@@ -44,6 +45,131 @@ class Swish(nn.Module):
         return SwishEfficient.apply(x)
 
 
+class _SESwishFunction(torch.autograd.Function):
+    """out = swish(a * sigmoid(fc2(relu(fc1(mean_thw a)))))   (Bottleneck3D.forward, resnet.py:182-190)."""
+
+    @staticmethod
+    def forward(ctx, a, w1, b1, w2, b2):
+        ops.require_cuda(a, w1, b1, w2, b2)
+        a = ops.f32(a).contiguous()
+        Nn, Cc = a.shape[0], a.shape[1]
+        thw = a.numel() // (Nn * Cc)
+        Wd = w1.shape[0]
+        w1m = w1.reshape(Wd, Cc).contiguous(); w2m = w2.reshape(Cc, Wd).contiguous()
+        pool = torch.empty(Nn, Cc, device=a.device); hidden = torch.empty(Nn, Wd, device=a.device)
+        gate = torch.empty(Nn, Cc, device=a.device); out = torch.empty_like(a)
+        N.check(N.lib().md_se_swish_fwd(ops._p(a), Nn, Cc, thw, Wd, ops._p(w1m), ops._p(b1.contiguous()), ops._p(w2m),
+                                        ops._p(b2.contiguous()), ops._p(pool), ops._p(hidden), ops._p(gate), ops._p(out),
+                                        ops._stream()), "md_se_swish_fwd")
+        ctx.save_for_backward(a, w1m, w2m, pool, hidden, gate)
+        ctx.wshapes = (w1.shape, w2.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, w1m, w2m, pool, hidden, gate = ctx.saved_tensors
+        Nn, Cc = a.shape[0], a.shape[1]
+        thw = a.numel() // (Nn * Cc)
+        Wd = w1m.shape[0]
+        g = ops.f32(dout).contiguous()
+        da = torch.empty_like(a)
+        dw1 = torch.empty_like(w1m); db1 = torch.empty(Wd, device=a.device)
+        dw2 = torch.empty_like(w2m); db2 = torch.empty(Cc, device=a.device)
+        scratch = torch.empty(3 * Nn * Cc + Nn * Wd, device=a.device)
+        N.check(N.lib().md_se_swish_bwd(ops._p(a), ops._p(g), Nn, Cc, thw, Wd, ops._p(w1m), ops._p(w2m), ops._p(pool),
+                                        ops._p(hidden), ops._p(gate), ops._p(da), ops._p(dw1), ops._p(db1), ops._p(dw2),
+                                        ops._p(db2), ops._p(scratch), ops._stream()), "md_se_swish_bwd")
+        s1, s2 = ctx.wshapes
+        return da, dw1.reshape(s1), db1, dw2.reshape(s2), db2
+
+
+class _AddReluFunction(torch.autograd.Function):
+    """relu(a + b): the residual close (resnet.py:196-198)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ops.require_cuda(a, b)
+        a = ops.f32(a).contiguous(); b = ops.f32(b).contiguous()
+        out = torch.empty_like(a)
+        N.check(N.lib().md_add_relu_fwd(ops._p(a), ops._p(b), a.numel(), ops._p(out), ops._stream()), "md_add_relu_fwd")
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (out,) = ctx.saved_tensors
+        g = ops.f32(dout).contiguous()
+        dx = torch.empty_like(out)
+        N.check(N.lib().md_add_relu_bwd(ops._p(out), ops._p(g), out.numel(), ops._p(dx), ops._stream()), "md_add_relu_bwd")
+        return dx, dx
+
+
+class Bottleneck3D(nn.Module):
+    """MI355X-native mirror of the reference's Bottleneck3D (resnet.py:121-200): same constructor, child-module names and
+    state-dict keys; every convolution + BatchNorm (+ReLU) runs as one gfx950 unit (``_unit.conv_bn_leaky`` with slope 0 /
+    1), the squeeze-excitation gate with Swish and the residual close as fused kernels.  ``base_bn_splits`` (SubBatchNorm3d)
+    and ``bias=True`` are not built."""
+    expansion = 4
+
+    def __init__(self, in_planes: int, planes: int, stride: int = 1, downsample=None, bias: bool = False, head_conv: int = 1,
+                 base_bn_splits=None, index: int = 0):
+        super(Bottleneck3D, self).__init__()
+        if base_bn_splits is not None:
+            raise NotImplementedError("mi355x hot path: SubBatchNorm3d (base_bn_splits) is not built")
+        if bias:
+            raise NotImplementedError("mi355x hot path: Bottleneck3D with bias=True is not used by the reference")
+        self.index = index
+        if head_conv == 1:
+            self.conv1 = nn.Conv3d(in_planes, planes, kernel_size=1, bias=False)
+        elif head_conv == 3:
+            self.conv1 = nn.Conv3d(in_planes, planes, kernel_size=(3, 1, 1), bias=False, padding=(1, 0, 0))
+        else:
+            raise ValueError("Unsupported head_conv!")
+        self.bn1 = nn.BatchNorm3d(planes)
+        self.conv2 = nn.Conv3d(planes, planes, kernel_size=(1, 3, 3), stride=(1, stride, stride), padding=(0, 1, 1), bias=bias)
+        self.bn2 = nn.BatchNorm3d(planes)
+        self.conv3 = nn.Conv3d(planes, planes * 4, kernel_size=1, bias=bias)
+        self.bn3 = nn.BatchNorm3d(planes * 4)
+        self.swish = Swish()
+        self.relu = nn.ReLU(inplace=True)
+        if self.index % 2 == 0:
+            width = self.round_width(planes)
+            self.global_pool = nn.AdaptiveAvgPool3d((1, 1, 1))
+            self.fc1 = nn.Conv3d(planes, width, kernel_size=1, stride=1)
+            self.fc2 = nn.Conv3d(width, planes, kernel_size=1, stride=1)
+            self.sigmoid = nn.Sigmoid()
+        self.downsample = downsample
+        self.stride = stride
+
+    def round_width(self, width: int, multiplier=0.0625, min_width=8, divisor=8):
+        if not multiplier:
+            return width
+        width *= multiplier
+        min_width = min_width or divisor
+        width_out = max(min_width, int(width + divisor / 2) // divisor * divisor)
+        if width_out < 0.9 * width:
+            width_out += divisor
+        return int(width_out)
+
+    def _downsample(self, x):
+        ds = self.downsample
+        if (isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[0], nn.Conv3d) and isinstance(ds[1], nn.BatchNorm3d)
+                and ds[0].bias is None):
+            return conv_bn_leaky(x, ds[0], ds[1], 1.0, self.training)          # conv + BN, no activation (resnet.py:254-257)
+        raise NotImplementedError("mi355x hot path: downsample must be Sequential(Conv3d(bias=False), BatchNorm3d)")
+
+    def forward(self, x):
+        out = conv_bn_leaky(x, self.conv1, self.bn1, 0.0, self.training)       # conv1 -> bn1 -> relu
+        out = conv_bn_leaky(out, self.conv2, self.bn2, 0.0, self.training)     # conv2 -> bn2 -> relu
+        if self.index % 2 == 0:
+            out = _SESwishFunction.apply(out, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+        else:
+            out = SwishEfficient.apply(out)
+        out = conv_bn_leaky(out, self.conv3, self.bn3, 1.0, self.training)     # conv3 -> bn3
+        residual = x if self.downsample is None else self._downsample(x)
+        return _AddReluFunction.apply(out, residual)
+
+
 def _adopt_reference():
     ref = _os.environ.get("MD_REFERENCE_SRC")
     path = _os.path.join(ref, "models", "resnet.py") if ref else None
@@ -56,8 +182,9 @@ def _adopt_reference():
     mod.SwishEfficient = SwishEfficient
     g = globals()
     for name in dir(mod):
-        if not name.startswith("_") and name not in ("Swish", "SwishEfficient"):
+        if not name.startswith("_") and name not in ("Swish", "SwishEfficient", "Bottleneck3D"):
             g.setdefault(name, getattr(mod, name))
+    mod.Bottleneck3D = Bottleneck3D
 
 
 _adopt_reference()

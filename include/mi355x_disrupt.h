@@ -178,6 +178,18 @@ int md_swish_bwd(const float* x, const float* dy, int64_t n, float* dx, void* st
 /* NoiseLayer, training branch (src/models/NoiseLayer.py:12-14): out = x + (mean + noise * std); `noise` holds the
  * standard-normal draws (the reference draws them with the CPU generator; the caller keeps that choice). */
 int md_add_noise(const float* x, const float* noise, float mean, float std, int64_t n, float* out, void* stream);
+/* Squeeze-and-excitation gate + Swish of Bottleneck3D (src/models/resnet.py:182-190) on (N,C,T,H,W) tensors:
+ * pool = mean_thw a; hidden = relu(W1 pool + b1) [N][Wd]; gate = sigmoid(W2 hidden + b2) [N][C]; out = swish(a * gate).
+ * W1 = fc1.weight as [Wd][C], W2 = fc2.weight as [C][Wd].  pool / hidden / gate are kept by the caller for the backward,
+ * which returns da, dW1, db1, dW2, db2 (scratch: 3*N*C + N*Wd floats).  Fixed-order reductions. */
+int md_se_swish_fwd(const float* a, int32_t N, int32_t C, int64_t thw, int32_t Wd, const float* w1, const float* b1,
+                    const float* w2, const float* b2, float* pool, float* hidden, float* gate, float* out, void* stream);
+int md_se_swish_bwd(const float* a, const float* dout, int32_t N, int32_t C, int64_t thw, int32_t Wd, const float* w1,
+                    const float* w2, const float* pool, const float* hidden, const float* gate, float* da, float* dw1,
+                    float* db1, float* dw2, float* db2, float* scratch, void* stream);
+/* Residual close of Bottleneck3D (resnet.py:196-198): out = relu(a + b); dx = dout * (out > 0) for both inputs. */
+int md_add_relu_fwd(const float* a, const float* b, int64_t n, float* out, void* stream);
+int md_add_relu_bwd(const float* out, const float* dout, int64_t n, float* dx, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimizer step: torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm) + torch.optim.AdamW.step()

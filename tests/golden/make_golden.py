@@ -244,6 +244,44 @@ def elementwise_fixture():
     print("elementwise", float(np.abs(out["swish_y"]).max()), float(np.abs(out["noise_train"] - xn).mean()))
 
 
+def bottleneck_fixture(tag, in_planes, planes, stride, head_conv, index, with_ds, shape, seed):
+    """Bottleneck3D (resnet.py:121-200) of the reference: state dict (its own seeded init, BN affine randomised so that the
+    scale/shift paths are exercised), input, output, input gradient, parameter gradients, running statistics after the step."""
+    from src.models.resnet import Bottleneck3D
+    import torch.nn as nn
+    torch.manual_seed(seed)
+    ds = None
+    if with_ds:
+        ds = nn.Sequential(nn.Conv3d(in_planes, planes * 4, kernel_size=1, stride=(1, stride, stride), bias=False),
+                           nn.BatchNorm3d(planes * 4))
+    m = Bottleneck3D(in_planes, planes, stride, ds, head_conv=head_conv, index=index)
+    with torch.no_grad():
+        for k, v in m.named_parameters():
+            if ".weight" in k and v.dim() == 1:
+                v.uniform_(0.5, 1.5)
+            elif k.endswith(".bias") and ("bn" in k or "downsample.1" in k):
+                v.normal_(0.0, 0.3)
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m.train()
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.randn(*shape, generator=g).requires_grad_(True)
+    out = m(x)
+    dout = torch.randn(out.shape, generator=g)
+    out.backward(dout)
+    rec = {"in_planes": in_planes, "planes": planes, "stride": stride, "head_conv": head_conv, "index": index,
+           "with_ds": int(with_ds), "x": x.detach().numpy(), "dout": dout.numpy(), "out": out.detach().numpy(),
+           "dx": x.grad.numpy()}
+    for k, v in sd0.items():
+        rec["sd/" + k] = v.numpy()
+    for k, p in m.named_parameters():
+        rec["grad/" + k] = p.grad.numpy()
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            rec["after/" + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, tag + ".npz"), **rec)
+    print(tag, tuple(out.shape), float(out.abs().max()))
+
+
 if __name__ == "__main__":
     # Several seeds per configuration: LeakyReLU(0.01) makes the gradient discontinuous where a
     # pre-activation crosses zero, so two correct fp32 implementations can disagree by >1e-3 on a whole
@@ -259,3 +297,5 @@ if __name__ == "__main__":
     drw_fixture()
     step_fixture()
     elementwise_fixture()
+    bottleneck_fixture("bottleneck3d_se_ds", 16, 8, 2, 3, 0, True, (2, 16, 4, 12, 12), 31)
+    bottleneck_fixture("bottleneck3d_plain", 32, 8, 1, 1, 1, False, (3, 32, 3, 8, 8), 32)

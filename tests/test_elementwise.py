@@ -71,6 +71,7 @@ def test_resnet_module_adopts_the_reference_for_unbuilt_names(tmp_path):
     code = ("import src.models.resnet as r\n"
             "b = r.Bottleneck3D(16, 4, index=0)\n"
             "assert type(b.swish) is r.Swish and r.Swish.__module__ == 'src.models.resnet'\n"
+            "assert r.Bottleneck3D.__module__ == 'src.models.resnet' and hasattr(r, 'ResNet3D')\n"
             "assert r.Swish().forward.__func__.__globals__['SwishEfficient'] is r.SwishEfficient\n"
             "print('ok', len([n for n in dir(r) if not n.startswith('_')]))\n")
     env = dict(os.environ, MD_REFERENCE_SRC=os.path.join(ref, "src"), PYTHONPATH=os.pathsep.join([pkg, str(tmp_path)]))

@@ -224,3 +224,81 @@ extern "C" int md_add_relu_bwd(const float* out, const float* dout, int64_t n, f
   MD_CHECK_LAUNCH();
   return MD_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Pieces of ResNet3D / SlowFast outside the bottleneck blocks (src/models/resnet.py:221-226, slowfast.py:33-34,86-87), on
+// (N,C,T,H,W) tensors: MaxPool3d((1,3,3), stride (1,2,2), padding (0,1,1)) and AdaptiveAvgPool3d(1).
+// ------------------------------------------------------------------------------------------------
+// forward: out[nct][ho][wo] = max over the 3x3 window (padding never wins: -inf); idx = flat h*W+w of the first maximum in
+// row-major window order (PyTorch's tie rule).  backward (gather form, deterministic): dx[h][w] = sum of dout over the
+// windows whose idx is (h,w).
+__global__ __launch_bounds__(256) void k_maxpool_fwd(const float* __restrict__ x, int64_t planes, int H, int W, int Ho, int Wo,
+                                                    float* __restrict__ out, int* __restrict__ idx) {
+  const int64_t n = planes * Ho * Wo;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int wo = (int)(i % Wo); const int64_t r = i / Wo; const int ho = (int)(r % Ho); const int64_t p = r / Ho;
+    const float* xp = x + p * H * W;
+    float best = -INFINITY; int bi = -1;
+    for (int dh = 0; dh < 3; ++dh) {
+      const int h = ho * 2 - 1 + dh; if (h < 0 || h >= H) continue;
+      for (int dw = 0; dw < 3; ++dw) {
+        const int w = wo * 2 - 1 + dw; if (w < 0 || w >= W) continue;
+        const float v = xp[h * W + w];
+        if (bi < 0 || v > best || v != v) { best = v; bi = h * W + w; }      // ATen's rule: (val > max) || isnan(val); first maximum wins
+      }
+    }
+    out[i] = best; idx[i] = bi;
+  }
+}
+__global__ __launch_bounds__(256) void k_maxpool_bwd(const float* __restrict__ dout, const int* __restrict__ idx, int64_t planes,
+                                                    int H, int W, int Ho, int Wo, float* __restrict__ dx) {
+  const int64_t n = planes * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int w = (int)(i % W); const int64_t r = i / W; const int h = (int)(r % H); const int64_t p = r / H;
+    const int me = h * W + w;
+    float s = 0.f;
+    // windows ho with 2*ho-1 <= h <= 2*ho+1  <=>  ho in [ceil((h-1)/2), floor((h+1)/2)]
+    for (int ho = (h >= 1 ? (h - 1 + 1) / 2 : 0); ho <= (h + 1) / 2 && ho < Ho; ++ho)
+      for (int wo = (w >= 1 ? (w - 1 + 1) / 2 : 0); wo <= (w + 1) / 2 && wo < Wo; ++wo) {
+        const int64_t o = (p * Ho + ho) * Wo + wo;
+        if (idx[o] == me) s += dout[o];
+      }
+    dx[i] = s;
+  }
+}
+// dx[row][i] = dmean[row] / thw
+__global__ __launch_bounds__(256) void k_rowmean_bwd(const float* __restrict__ dmean, int64_t thw, int64_t n, float* __restrict__ dx) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dx[i] = dmean[i / thw] / (float)thw;
+}
+
+extern "C" int md_maxpool_1x3x3_fwd(const float* x, int64_t planes, int32_t H, int32_t W, float* out, int32_t* idx, void* stream) {
+  if (!x || !out || !idx) return MD_ERR_NULL;
+  if (planes <= 0 || H <= 0 || W <= 0) return MD_ERR_BAD_SHAPE;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  MD_KLAUNCH(k_maxpool_fwd, dim3(elem_blocks(planes * Ho * Wo * 4)), dim3(256), 0, (hipStream_t)stream, x, planes, H, W, Ho, Wo, out, idx);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+extern "C" int md_maxpool_1x3x3_bwd(const float* dout, const int32_t* idx, int64_t planes, int32_t H, int32_t W, float* dx, void* stream) {
+  if (!dout || !idx || !dx) return MD_ERR_NULL;
+  if (planes <= 0 || H <= 0 || W <= 0) return MD_ERR_BAD_SHAPE;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  MD_KLAUNCH(k_maxpool_bwd, dim3(elem_blocks(planes * H * W * 4)), dim3(256), 0, (hipStream_t)stream, dout, idx, planes, H, W, Ho, Wo, dx);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+extern "C" int md_rowmean_fwd(const float* x, int64_t rows, int64_t thw, float* mean, void* stream) {
+  if (!x || !mean) return MD_ERR_NULL;
+  if (rows <= 0 || thw <= 0 || rows > 0x7fffffff) return MD_ERR_BAD_SHAPE;
+  MD_KLAUNCH(k_row_reduce<0>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, (const float*)nullptr,
+             (const float*)nullptr, thw, mean);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+extern "C" int md_rowmean_bwd(const float* dmean, int64_t rows, int64_t thw, float* dx, void* stream) {
+  if (!dmean || !dx) return MD_ERR_NULL;
+  if (rows <= 0 || thw <= 0) return MD_ERR_BAD_SHAPE;
+  MD_KLAUNCH(k_rowmean_bwd, dim3(elem_blocks(rows * thw * 4)), dim3(256), 0, (hipStream_t)stream, dmean, thw, rows * thw, dx);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}

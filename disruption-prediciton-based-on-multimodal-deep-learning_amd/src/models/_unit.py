@@ -104,3 +104,89 @@ class HeadFunction(torch.autograd.Function):
                                     ops._p(save), ops._p(df), ops._p(dw0), ops._p(db0), ops._p(dg), ops._p(dbt), ops._p(dw1),
                                     ops._p(db1), ops._stream()), "md_head_bwd")
         return df, dw0, db0, dg, dbt, dw1, db1, None, None, None, None, None, None
+
+
+class ConvFunction(torch.autograd.Function):
+    """Plain Conv3d (no bias, no normalisation): the SlowFast laterals (reference slowfast.py:58-65)."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, padding):
+        ops.require_cuda(x, w)
+        B, Cin, T, H, W = x.shape
+        Cout = w.shape[0]
+        d = ops.make_desc(B, T, H, W, Cin, Cout, tuple(w.shape[2:]), tuple(stride), tuple(padding))
+        xcl = ops.to_channels_last(x.contiguous().float())
+        wf, wd = ops.pack_weights(d, w.contiguous(), want_dgrad=True)
+        y, _ = ops.conv_fwd(d, ops.view(xcl), wf, x.device, want_stats=False)
+        ctx.d = d
+        ctx.save_for_backward(xcl, wd)
+        return ops.from_channels_last(y, Cout)
+
+    @staticmethod
+    def backward(ctx, dout):
+        xcl, wd = ctx.saved_tensors
+        d = ctx.d
+        dy = ops.to_channels_last(dout.contiguous().float())
+        dw = ops.conv_wgrad(d, ops.view(xcl), dy)
+        dx = ops.from_channels_last(ops.conv_dgrad(d, dy, wd), d.Cin) if ctx.needs_input_grad[0] else None
+        return dx, dw, None, None
+
+
+def conv_plain(x, conv: torch.nn.Conv3d):
+    if conv.bias is not None:
+        raise NotImplementedError("mi355x hot path: plain convolution with bias is not used by the reference")
+    return ConvFunction.apply(x, conv.weight, conv.stride, conv.padding)
+
+
+class MaxPool1x3x3Function(torch.autograd.Function):
+    """MaxPool3d((1,3,3), stride (1,2,2), padding (0,1,1))   (reference resnet.py:225)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ops.require_cuda(x)
+        x = ops.f32(x).contiguous()
+        B, Cc, T, H, W = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        out = torch.empty((B, Cc, T, Ho, Wo), device=x.device, dtype=torch.float32)
+        idx = torch.empty((B, Cc, T, Ho, Wo), device=x.device, dtype=torch.int32)
+        N.check(N.lib().md_maxpool_1x3x3_fwd(ops._p(x), B * Cc * T, H, W, ops._p(out), ops._p(idx), ops._stream()),
+                "md_maxpool_1x3x3_fwd")
+        ctx.save_for_backward(idx)
+        ctx.shape = (B, Cc, T, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        B, Cc, T, H, W = ctx.shape
+        g = ops.f32(dout).contiguous()
+        dx = torch.empty(ctx.shape, device=g.device, dtype=torch.float32)
+        N.check(N.lib().md_maxpool_1x3x3_bwd(ops._p(g), ops._p(idx), B * Cc * T, H, W, ops._p(dx), ops._stream()),
+                "md_maxpool_1x3x3_bwd")
+        return dx
+
+
+class GlobalAvgPoolFunction(torch.autograd.Function):
+    """F.adaptive_avg_pool3d(x, 1).view(-1, C)   (reference slowfast.py:33-34, 86-87)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ops.require_cuda(x)
+        x = ops.f32(x).contiguous()
+        B, Cc = x.shape[0], x.shape[1]
+        thw = x.numel() // (B * Cc)
+        out = torch.empty((B, Cc), device=x.device, dtype=torch.float32)
+        N.check(N.lib().md_rowmean_fwd(ops._p(x), B * Cc, thw, ops._p(out), ops._stream()), "md_rowmean_fwd")
+        ctx.shape = tuple(x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        g = ops.f32(dout).contiguous()
+        B, Cc = ctx.shape[0], ctx.shape[1]
+        thw = 1
+        for s in ctx.shape[2:]:
+            thw *= s
+        dx = torch.empty(ctx.shape, device=g.device, dtype=torch.float32)
+        N.check(N.lib().md_rowmean_bwd(ops._p(g), B * Cc, thw, ops._p(dx), ops._stream()), "md_rowmean_bwd")
+        return dx

@@ -190,6 +190,14 @@ int md_se_swish_bwd(const float* a, const float* dout, int32_t N, int32_t C, int
 /* Residual close of Bottleneck3D (resnet.py:196-198): out = relu(a + b); dx = dout * (out > 0) for both inputs. */
 int md_add_relu_fwd(const float* a, const float* b, int64_t n, float* out, void* stream);
 int md_add_relu_bwd(const float* out, const float* dout, int64_t n, float* dx, void* stream);
+/* MaxPool3d(kernel (1,3,3), stride (1,2,2), padding (0,1,1)) of ResNet3D.layer0 (resnet.py:225) on `planes` = N*C*T
+ * planes of H x W; idx keeps the flat h*W+w of the maximum (first one wins, NaN propagates, as ATen); the backward sums
+ * dout over the windows that selected each input (gather form, deterministic). */
+int md_maxpool_1x3x3_fwd(const float* x, int64_t planes, int32_t H, int32_t W, float* out, int32_t* idx, void* stream);
+int md_maxpool_1x3x3_bwd(const float* dout, const int32_t* idx, int64_t planes, int32_t H, int32_t W, float* dx, void* stream);
+/* F.adaptive_avg_pool3d(x, 1) on (N,C,T,H,W) (slowfast.py:33,86): mean[row] over the thw values of each (n,c) row. */
+int md_rowmean_fwd(const float* x, int64_t rows, int64_t thw, float* mean, void* stream);
+int md_rowmean_bwd(const float* dmean, int64_t rows, int64_t thw, float* dx, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimizer step: torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm) + torch.optim.AdamW.step()

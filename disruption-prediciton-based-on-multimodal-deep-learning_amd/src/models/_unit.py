@@ -18,6 +18,7 @@ from .. import ops
 class ConvBnLeakyFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, gamma, beta, rmean, rvar, stride, padding, slope, training, eps, momentum):
+        x = x.contiguous()                   # (strided views such as x[:, :, ::tau] are packed here: memory plumbing)
         ops.require_cuda(x, w, gamma, beta)
         B, Cin, T, H, W = x.shape
         Cout = w.shape[0]
@@ -111,6 +112,7 @@ class ConvFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, stride, padding):
+        x = x.contiguous()
         ops.require_cuda(x, w)
         B, Cin, T, H, W = x.shape
         Cout = w.shape[0]

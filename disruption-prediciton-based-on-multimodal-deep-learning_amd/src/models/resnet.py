@@ -1,8 +1,8 @@
 """MI355X-native pieces of the reference's ``src/models/resnet.py``.
 
-Built here: ``SwishEfficient`` / ``Swish`` (resnet.py:63-81) on ``md_swish_fwd`` / ``md_swish_bwd`` and ``Bottleneck3D``
-(resnet.py:121-200).  The rest of that module (BasicBlock3D, ResNet3D, SubBatchNorm3d,
-Bottleneck2DPlus1D, ...) is not rebuilt yet (row a7).  When ``MD_REFERENCE_SRC`` points at the reference's ``src`` directory those names are
+Built here: ``SwishEfficient`` / ``Swish`` (resnet.py:63-81) on ``md_swish_fwd`` / ``md_swish_bwd`` , ``Bottleneck3D``
+(resnet.py:121-200) and the ``ResNet3D`` base (resnet.py:202-273).  The rest of that module
+(BasicBlock3D, SubBatchNorm3d, Bottleneck2DPlus1D, ...) is not used by the SlowFast configuration and is not rebuilt.  When ``MD_REFERENCE_SRC`` points at the reference's ``src`` directory those names are
 loaded from the reference file and re-exported with ITS ``Swish`` / ``SwishEfficient`` / ``Bottleneck3D`` replaced by the ones below, so
 ``from src.models.resnet import *`` (slowfast.py:5) keeps working and the reference's SlowFast runs its Swish on the
 gfx950 kernel.  Without it this module exports the two native names only.
@@ -170,6 +170,99 @@ class Bottleneck3D(nn.Module):
         return _AddReluFunction.apply(out, residual)
 
 
+class _AbsorbedBias(torch.autograd.Function):
+    """A convolution bias in front of a training-mode BatchNorm cancels in the output; its gradient is exactly zero."""
+
+    @staticmethod
+    def forward(ctx, out, bias):
+        ctx.n = bias.numel()
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, dout):
+        return dout, torch.zeros(ctx.n, device=dout.device, dtype=dout.dtype)
+
+
+def _conv_bias_bn_relu(x, conv: nn.Conv3d, bn: nn.BatchNorm3d, training: bool):
+    """Conv3d(bias=True) -> BatchNorm3d -> ReLU (ResNet3D.layer0, resnet.py:221-224) on the bias-free gfx950 unit: the bias
+    only shifts the batch mean, so it is folded into the running mean (kept identical to the reference's, state dicts
+    stay interchangeable) and gets its exact zero gradient."""
+    if conv.bias is None:
+        return conv_bn_leaky(x, conv, bn, 0.0, training)
+    from ._unit import ConvBnLeakyFunction
+    b = conv.bias.detach()
+    rmean = bn.running_mean if training else bn.running_mean - b              # eval: (y + b - rm) == (y - (rm - b))
+    out = ConvBnLeakyFunction.apply(x, conv.weight, bn.weight, bn.bias, rmean, bn.running_var, conv.stride, conv.padding, 0.0,
+                                    bool(training), float(bn.eps), float(bn.momentum))
+    if training:
+        bn.running_mean.add_(b * bn.momentum)                                  # the batch mean of (y + b) is mean(y) + b
+        bn.num_batches_tracked += 1
+        out = _AbsorbedBias.apply(out, conv.bias)
+    return out
+
+
+class ResNet3D(nn.Module):
+    """Mirror of the reference's ResNet3D base (resnet.py:202-273): same constructor keywords (in_channels, alpha, slow,
+    base_bn_splits), same children (layer0 .. layer4).  ``forward`` is left to SlowNet / FastNet as in the reference; the
+    stem runs through ``stem()`` (conv+BN+ReLU unit, then the (1,3,3)/2 max pool kernel)."""
+
+    def __init__(self, block, layers, **kwargs):
+        super(ResNet3D, self).__init__()
+        in_channels = kwargs['in_channels']
+        self.alpha = kwargs['alpha']
+        self.slow = kwargs['slow']  # slow->1 else fast->0
+        m = 16
+        self.inplanes = (m + m // self.alpha) if self.slow else m // self.alpha
+        self.base_bn_splits = kwargs["base_bn_splits"]
+        out_channels = m // (1 if self.slow else self.alpha)
+        self.layer0 = nn.Sequential(
+            nn.Conv3d(in_channels, out_channels, kernel_size=(1, 7, 7), stride=(1, 2, 2), padding=(0, 3, 3)),
+            nn.BatchNorm3d(out_channels),
+            nn.ReLU(inplace=True),
+            nn.MaxPool3d(kernel_size=(1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1))
+        )
+        self.layer1 = self._make_layer(block, m // (1 if self.slow else self.alpha), layers[0],
+                                       head_conv=1 if self.slow else 3, base_bn_splits=self.base_bn_splits)
+        self.layer2 = self._make_layer(block, 2 * m // (1 if self.slow else self.alpha), layers[1], stride=2,
+                                       head_conv=1 if self.slow else 3, base_bn_splits=self.base_bn_splits)
+        self.layer3 = self._make_layer(block, 4 * m // (1 if self.slow else self.alpha), layers[2], stride=2,
+                                       head_conv=3, base_bn_splits=self.base_bn_splits)
+        self.layer4 = self._make_layer(block, 8 * m // (1 if self.slow else self.alpha), layers[3], stride=2,
+                                       head_conv=3, base_bn_splits=self.base_bn_splits)
+
+    def init_params(self):
+        import torch.nn.init as nn_init
+        for m in self.modules():
+            if isinstance(m, nn.Conv3d):
+                nn_init.xavier_normal_(m.weight)
+            elif isinstance(m, nn.BatchNorm3d) and m.weight is not None:
+                nn_init.constant_(m.weight, 1)
+
+    def stem(self, x):
+        from ._unit import MaxPool1x3x3Function
+        x = _conv_bias_bn_relu(x, self.layer0[0], self.layer0[1], self.training)
+        return MaxPool1x3x3Function.apply(x)
+
+    def forward(self, x):
+        raise NotImplementedError('use each pathway network\' forward function')
+
+    def _make_layer(self, block, planes: int, blocks: int = 3, stride: int = 1, head_conv: int = 1, base_bn_splits=None):
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(
+                nn.Conv3d(self.inplanes, planes * block.expansion, kernel_size=1, stride=(1, stride, stride), bias=False),
+                nn.BatchNorm3d(planes * block.expansion)
+            )
+        else:
+            downsample = None
+        layers = list()
+        layers.append(block(self.inplanes, planes, stride, downsample, head_conv=head_conv, base_bn_splits=base_bn_splits))
+        self.inplanes = planes * block.expansion
+        for i in range(1, blocks):
+            layers.append(block(self.inplanes, planes, head_conv=head_conv, base_bn_splits=base_bn_splits))
+        self.inplanes += self.slow * block.expansion * planes // self.alpha
+        return nn.Sequential(*layers)
+
+
 def _adopt_reference():
     ref = _os.environ.get("MD_REFERENCE_SRC")
     path = _os.path.join(ref, "models", "resnet.py") if ref else None
@@ -182,7 +275,7 @@ def _adopt_reference():
     mod.SwishEfficient = SwishEfficient
     g = globals()
     for name in dir(mod):
-        if not name.startswith("_") and name not in ("Swish", "SwishEfficient", "Bottleneck3D"):
+        if not name.startswith("_") and name not in ("Swish", "SwishEfficient", "Bottleneck3D", "ResNet3D"):
             g.setdefault(name, getattr(mod, name))
     mod.Bottleneck3D = Bottleneck3D
 

@@ -1,0 +1,160 @@
+"""MI355X-native mirror of the reference's ``src/models/slowfast.py`` (same classes, constructor arguments, child-module
+names and state-dict keys: ``encoder.slownet.layer4[0].downsample[0]``, ``encoder.fastnet.l_layer3``, ``classifier.classifier``).
+
+Every convolution + BatchNorm runs as a gfx950 unit (Bottleneck3D / ResNet3D in ``resnet.py``), the laterals as plain
+convolutions, the pools and the classifier head as fused kernels.  ``torch.cat`` and the temporal sub-sampling
+``x[:, :, ::tau]`` are memory plumbing and stay torch calls.  Differences a maintainer should know: inputs must be CUDA
+tensors (no CPU dummy forward: the classifier width is computed from the architecture, 128*m/alpha... = 512 + 128 = 640 for
+the defaults, instead of ``get_output_shape()`` tracing a CPU sample, slowfast.py:186-187).
+"""
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .resnet import *          # noqa: F401,F403  (as the reference does, slowfast.py:5)
+from .resnet import Bottleneck3D, ResNet3D
+from ._unit import GlobalAvgPoolFunction, HeadFunction, conv_plain
+
+
+class SlowNet(ResNet3D):
+    def __init__(self, blocks, layers, **kwargs):
+        super(SlowNet, self).__init__(blocks, layers, **kwargs)
+        self.init_params()
+
+    def forward(self, x: Tuple[torch.Tensor, List[torch.Tensor]]):
+        x, laterals = x
+        x = self.stem(x)
+        x = torch.cat([x, laterals[0]], dim=1)
+        x = self.layer1(x)
+        x = torch.cat([x, laterals[1]], dim=1)
+        x = self.layer2(x)
+        x = torch.cat([x, laterals[2]], dim=1)
+        x = self.layer3(x)
+        x = torch.cat([x, laterals[3]], dim=1)
+        x = self.layer4(x)
+        return GlobalAvgPoolFunction.apply(x)
+
+
+def resnet50_s(block=Bottleneck3D, layers=[3, 4, 6, 3], **kwargs):
+    return SlowNet(block, layers, **kwargs)
+
+
+class FastNet(ResNet3D):
+    def __init__(self, blocks, layers, **kwargs):
+        super(FastNet, self).__init__(blocks, layers, **kwargs)
+        alpha = kwargs["alpha"]
+        kernel_size = (alpha + 2, 1, 1)
+        stride = (alpha, 1, 1)
+        padding = (1, 0, 0)
+        m = 16
+        self.l_maxpool = nn.Conv3d(m // self.alpha, m // self.alpha, kernel_size=kernel_size, stride=stride, bias=False,
+                                   padding=padding)
+        self.l_layer1 = nn.Conv3d(4 * m // self.alpha, 4 * m // self.alpha, kernel_size=kernel_size, stride=stride, bias=False,
+                                  padding=padding)
+        self.l_layer2 = nn.Conv3d(8 * m // self.alpha, 8 * m // self.alpha, kernel_size=kernel_size, stride=stride, bias=False,
+                                  padding=padding)
+        self.l_layer3 = nn.Conv3d(16 * m // self.alpha, 16 * m // self.alpha, kernel_size=kernel_size, stride=stride,
+                                  bias=False, padding=padding)
+        self.init_params()
+
+    def forward(self, x: torch.Tensor):
+        laterals = []
+        x = self.stem(x)
+        laterals.append(conv_plain(x, self.l_maxpool))
+        x = self.layer1(x)
+        laterals.append(conv_plain(x, self.l_layer1))
+        x = self.layer2(x)
+        laterals.append(conv_plain(x, self.l_layer2))
+        x = self.layer3(x)
+        laterals.append(conv_plain(x, self.l_layer3))
+        x = self.layer4(x)
+        return GlobalAvgPoolFunction.apply(x), laterals
+
+
+def resnet50_f(block=Bottleneck3D, layers=[3, 4, 6, 3], **kwargs):
+    return FastNet(block, layers, **kwargs)
+
+
+class SlowFastEncoder(nn.Module):
+    def __init__(self, input_shape: Tuple[int, int, int, int] = (3, 8, 112, 112), block=Bottleneck3D,
+                 layers: List[int] = [3, 4, 6, 3], alpha: int = 4, tau_fast: int = 1):
+        super(SlowFastEncoder, self).__init__()
+        self.input_shape = input_shape
+        self.seq_len = input_shape[1]
+        self.in_channels = input_shape[0]
+        self.alpha = alpha
+        self.tau_fast = tau_fast
+        self.slownet = resnet50_s(block=block, layers=layers, alpha=alpha, in_channels=self.in_channels, slow=1,
+                                  base_bn_splits=None)
+        self.fastnet = resnet50_f(block=block, layers=layers, alpha=alpha, in_channels=self.in_channels, slow=0,
+                                  base_bn_splits=None)
+        self._out_dim = 8 * 16 * block.expansion + 8 * 16 // alpha * block.expansion       # slow + fast pooled widths
+
+    def split_slow_fast(self, x: torch.Tensor):
+        tau_fast = self.tau_fast
+        tau_slow = tau_fast * self.alpha
+        return x[:, :, ::tau_slow, :, :], x[:, :, ::tau_fast, :, :]
+
+    def forward(self, x: torch.Tensor):
+        x_slow, x_fast = self.split_slow_fast(x)
+        x_fast, laterals = self.fastnet(x_fast)
+        x_slow = self.slownet((x_slow, laterals))
+        return torch.cat([x_slow, x_fast], dim=1)
+
+    def show_CAM(self):
+        pass
+
+    def show_Grad_CAM(self):
+        pass
+
+    def get_output_shape(self):
+        return torch.Size((1, self._out_dim))
+
+
+class SlowFastClassifier(nn.Module):
+    def __init__(self, input_dim: int, num_classes: int = 2, alpha: float = 1.0):
+        super(SlowFastClassifier, self).__init__()
+        self.input_dim = input_dim
+        self.classifier = nn.Sequential(
+            nn.Linear(input_dim, input_dim // 2),
+            nn.BatchNorm1d(input_dim // 2),
+            nn.ELU(alpha),
+            nn.Linear(input_dim // 2, num_classes)
+        )
+
+    def forward(self, x: torch.Tensor):
+        lin0, bn, elu, lin1 = self.classifier[0], self.classifier[1], self.classifier[2], self.classifier[3]
+        out = HeadFunction.apply(x, lin0.weight, lin0.bias, bn.weight, bn.bias, lin1.weight, lin1.bias, bn.running_mean,
+                                 bn.running_var, float(elu.alpha), float(bn.eps), float(bn.momentum), bool(self.training))
+        if self.training:
+            bn.num_batches_tracked += 1
+        return out
+
+
+class SlowFast(nn.Module):
+    def __init__(self, input_shape: Tuple[int, int, int, int] = (3, 8, 112, 112), block=Bottleneck3D,
+                 layers: List[int] = [3, 4, 6, 3], alpha: int = 4, tau_fast: int = 1, num_classes: int = 2,
+                 alpha_elu: float = 1.0):
+        super(SlowFast, self).__init__()
+        self.input_shape = input_shape
+        self.encoder = SlowFastEncoder(input_shape, block, layers, alpha, tau_fast)
+        cls_input_dim = self.encoder.get_output_shape()[-1]
+        self.classifier = SlowFastClassifier(cls_input_dim, num_classes, alpha_elu)
+
+    def encode(self, x: torch.Tensor):
+        with torch.no_grad():
+            x = self.encoder.forward(x)
+            return x.view(x.size()[0], -1)
+
+    def forward(self, x: torch.Tensor):
+        x = self.encoder.forward(x)
+        return self.classifier.forward(x)
+
+    def summary(self, device: str = 'cpu', show_input: bool = True, show_hierarchical: bool = True, print_summary: bool = False,
+                show_parent_layers: bool = True):
+        rows = ["%-60s %-24s %d" % (k, tuple(v.shape), v.numel()) for k, v in self.named_parameters()]
+        text = "\\n".join(rows + ["total parameters: %d" % sum(p.numel() for p in self.parameters())])
+        if print_summary:
+            print(text)
+        return text

@@ -282,6 +282,33 @@ def bottleneck_fixture(tag, in_planes, planes, stride, head_conv, index, with_ds
     print(tag, tuple(out.shape), float(out.abs().max()))
 
 
+def slowfast_fixture():
+    """SlowFast (slowfast.py:165-196) of the reference at a tiny configuration.  Weights and the input come from the NumPy
+    recipes in oracle/slowfast.py (loaded with load_state_dict), so the fixture stores seeds plus the reference's logits,
+    sub-sampled gradients, gradient norms and the running statistics after one training-mode step."""
+    from src.models.slowfast import SlowFast
+    from oracle import slowfast as osf
+    layers, T, S, B, seed = [1, 1, 1, 1], 8, 64, 3, 41
+    m = SlowFast(input_shape=(3, T, S, S), layers=layers, alpha=4, tau_fast=1, num_classes=2, alpha_elu=1.0)
+    sd0 = osf.synth_state({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed)
+    m.load_state_dict(sd0, strict=True)
+    m.train()
+    x = osf.synth_clip(B, T, S, seed + 1)
+    logits = m(x)
+    dlog = torch.from_numpy(np.random.default_rng(seed + 2).standard_normal(tuple(logits.shape)).astype(np.float32))
+    logits.backward(dlog)
+    rec = {"layers": np.array(layers), "T": T, "S": S, "B": B, "seed": seed, "dlogits": dlog.numpy(),
+           "logits": logits.detach().numpy()}
+    for k, p in m.named_parameters():
+        rec["gsub/" + k] = subsample(p.grad)
+        rec["gnorm/" + k] = np.float64(p.grad.double().norm())
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            rec["after/" + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "slowfast_tiny.npz"), **rec)
+    print("slowfast", logits.detach().numpy())
+
+
 if __name__ == "__main__":
     # Several seeds per configuration: LeakyReLU(0.01) makes the gradient discontinuous where a
     # pre-activation crosses zero, so two correct fp32 implementations can disagree by >1e-3 on a whole
@@ -299,3 +326,4 @@ if __name__ == "__main__":
     elementwise_fixture()
     bottleneck_fixture("bottleneck3d_se_ds", 16, 8, 2, 3, 0, True, (2, 16, 4, 12, 12), 31)
     bottleneck_fixture("bottleneck3d_plain", 32, 8, 1, 1, 1, False, (3, 32, 3, 8, 8), 32)
+    slowfast_fixture()

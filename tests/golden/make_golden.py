@@ -309,6 +309,35 @@ def slowfast_fixture():
     print("slowfast", logits.detach().numpy())
 
 
+def gb_loops_fixture():
+    """GB_estimate (GradientBlending.py:52-114) and train_GB_dynamic (:310-446) of the reference on the tiny two-stream model
+    and loaders of oracle/fake_multimodal.py (CPU, SGD, summed cross entropy): the estimated weights, the loss histories and
+    the final blending weights."""
+    import tempfile
+    from src.GradientBlending import GB_estimate, GradientBlending, train_GB_dynamic
+    from oracle.fake_multimodal import FakeMultiModalGB, loaders
+    ce = lambda: torch.nn.CrossEntropyLoss(reduction="sum")
+    with tempfile.TemporaryDirectory() as d:
+        tr, va = loaders(11)
+        model = FakeMultiModalGB()
+        last = os.path.join(d, "last.pt"); best = os.path.join(d, "best.pt")
+        torch.save(model.state_dict(), last)
+        opt = torch.optim.SGD(model.parameters(), lr=0.05)
+        w = GB_estimate(2, tr, va, last, model, opt, None, ce(), "cpu", None)
+        rec = {"est/" + k: np.float64(v) for k, v in w.items()}
+        model = FakeMultiModalGB()
+        opt = torch.optim.SGD(model.parameters(), lr=0.05)
+        loss_gb = GradientBlending(ce(), ce(), ce(), 0.2, 0.3, 0.5, 1.0)
+        hist = train_GB_dynamic(tr, va, model, opt, None, loss_gb, ce(), "cpu", num_epoch=4, epoch_per_GB_estimate=2,
+                                num_epoch_GB_estimate=2, verbose=None, save_best_dir=best, save_last_dir=last,
+                                exp_dir=os.path.join(d, "exp"), max_norm_grad=1.0, criteria="loss")
+        for name, h in zip(("train_loss", "train_acc", "train_f1", "valid_loss", "valid_acc", "valid_f1"), hist):
+            rec["dyn/" + name] = np.array(h, dtype=np.float64)
+        rec["dyn/weights"] = np.array([loss_gb.vis_weight, loss_gb.ts_weight, loss_gb.vis_ts_weight], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "gb_loops.npz"), **rec)
+    print("gb loops", w, rec["dyn/weights"])
+
+
 if __name__ == "__main__":
     # Several seeds per configuration: LeakyReLU(0.01) makes the gradient discontinuous where a
     # pre-activation crosses zero, so two correct fp32 implementations can disagree by >1e-3 on a whole
@@ -327,3 +356,4 @@ if __name__ == "__main__":
     bottleneck_fixture("bottleneck3d_se_ds", 16, 8, 2, 3, 0, True, (2, 16, 4, 12, 12), 31)
     bottleneck_fixture("bottleneck3d_plain", 32, 8, 1, 1, 1, False, (3, 32, 3, 8, 8), 32)
     slowfast_fixture()
+    gb_loops_fixture()

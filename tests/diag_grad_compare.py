@@ -1,4 +1,4 @@
-"""Per-parameter gradient deviation of the HIP path vs the oracle in fp32 and fp64 for one golden fixture:\n    python tools/grad_compare.py r2p1d_1111_s2"""
+"""Per-parameter gradient deviation of the HIP path vs the oracle in fp32 and fp64 for one golden fixture:\n    python tests/diag_grad_compare.py r2p1d_1111_s2"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'disruption-prediciton-based-on-multimodal-deep-learning_amd'))

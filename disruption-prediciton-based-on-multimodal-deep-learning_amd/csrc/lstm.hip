@@ -1,0 +1,154 @@
+// One direction of one nn.LSTM layer (batch_first=False, zero initial state), forward and backward through time
+// (reference users: src/models/CnnLSTM.py:51,93-96 and src/models/MLSTM_FCN.py).
+// PyTorch conventions: gates in the order i, f, g, o; pre-activation = W_ih x_t + b_ih + W_hh h_{t-1} + b_hh;
+// c_t = f*c_{t-1} + i*g;  h_t = o * tanh(c_t).
+// The sequences are tiny (S <= a few dozen steps, H <= 128) and strictly sequential in time: one workgroup per batch element
+// walks the steps with h_{t-1} in LDS (latency-bound by construction); the weight gradients are a separate reduction over
+// all (t, b) pairs.  Everything is fixed-order fp32 (bitwise reproducible).
+#include "common.h"
+
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+
+// x [S][B][I], h_all / c_all [S][B][H], gates [S][B][4H] (activated i, f, g, o); reverse != 0 walks t = S-1 .. 0
+__global__ __launch_bounds__(256) void k_lstm_fwd(const float* __restrict__ x, const float* __restrict__ w_ih,
+                                                 const float* __restrict__ w_hh, const float* __restrict__ b_ih,
+                                                 const float* __restrict__ b_hh, int S, int B, int I, int H, int reverse,
+                                                 float* __restrict__ h_all, float* __restrict__ c_all, float* __restrict__ gates) {
+  extern __shared__ float sm[];
+  float* hprev = sm;            // [H]
+  float* cprev = sm + H;        // [H]
+  float* xs = sm + 2 * H;       // [I]
+  float* pre = xs + I;          // [4H]
+  const int b = blockIdx.x, t = threadIdx.x;
+  for (int k = t; k < H; k += 256) { hprev[k] = 0.f; cprev[k] = 0.f; }
+  for (int step = 0; step < S; ++step) {
+    const int ts = reverse ? S - 1 - step : step;
+    const float* xt = x + ((size_t)ts * B + b) * I;
+    for (int i = t; i < I; i += 256) xs[i] = xt[i];
+    __syncthreads();
+    for (int j = t; j < 4 * H; j += 256) {
+      float a = b_ih[j] + b_hh[j];
+      const float* wi = w_ih + (size_t)j * I; const float* wh = w_hh + (size_t)j * H;
+      for (int i = 0; i < I; ++i) a = fmaf(wi[i], xs[i], a);
+      for (int k = 0; k < H; ++k) a = fmaf(wh[k], hprev[k], a);
+      pre[j] = a;
+    }
+    __syncthreads();
+    float* gt = gates + ((size_t)ts * B + b) * 4 * H;
+    for (int k = t; k < H; k += 256) {
+      const float ig = sigm(pre[k]), fg = sigm(pre[H + k]), gg = tanhf(pre[2 * H + k]), og = sigm(pre[3 * H + k]);
+      const float c = fg * cprev[k] + ig * gg;
+      const float h = og * tanhf(c);
+      gt[k] = ig; gt[H + k] = fg; gt[2 * H + k] = gg; gt[3 * H + k] = og;
+      c_all[((size_t)ts * B + b) * H + k] = c;
+      h_all[((size_t)ts * B + b) * H + k] = h;
+      cprev[k] = c; hprev[k] = h;
+    }
+    __syncthreads();
+  }
+}
+
+// dh_all [S][B][H] = gradient w.r.t. every output h_t.  Writes dpre [S][B][4H] (gradient w.r.t. the gate pre-activations)
+// and dx [S][B][I].
+__global__ __launch_bounds__(256) void k_lstm_bwd(const float* __restrict__ dh_all, const float* __restrict__ w_ih,
+                                                 const float* __restrict__ w_hh, const float* __restrict__ c_all,
+                                                 const float* __restrict__ gates, int S, int B, int I, int H, int reverse,
+                                                 float* __restrict__ dpre, float* __restrict__ dx) {
+  extern __shared__ float sm[];
+  float* dh = sm;               // [H] recurrent part of dL/dh_t
+  float* dc = sm + H;           // [H] dL/dc_t carried backwards
+  float* dg = sm + 2 * H;       // [4H]
+  const int b = blockIdx.x, t = threadIdx.x;
+  for (int k = t; k < H; k += 256) { dh[k] = 0.f; dc[k] = 0.f; }
+  __syncthreads();
+  for (int step = S - 1; step >= 0; --step) {
+    const int ts = reverse ? S - 1 - step : step;                  // the step-th processed time index
+    const int tprev = reverse ? ts + 1 : ts - 1;                   // time index processed just before it (none at step 0)
+    const size_t row = (size_t)ts * B + b;
+    const float* gt = gates + row * 4 * H;
+    for (int k = t; k < H; k += 256) {
+      const float ig = gt[k], fg = gt[H + k], gg = gt[2 * H + k], og = gt[3 * H + k];
+      const float c = c_all[row * H + k];
+      const float cp = step > 0 ? c_all[((size_t)tprev * B + b) * H + k] : 0.f;
+      const float tc = tanhf(c);
+      const float dht = dh_all[row * H + k] + dh[k];
+      const float dct = dc[k] + dht * og * (1.f - tc * tc);
+      dg[k] = dct * gg * ig * (1.f - ig);                          // d pre_i
+      dg[H + k] = dct * cp * fg * (1.f - fg);                      // d pre_f
+      dg[2 * H + k] = dct * ig * (1.f - gg * gg);                  // d pre_g
+      dg[3 * H + k] = dht * tc * og * (1.f - og);                  // d pre_o
+      dc[k] = dct * fg;
+    }
+    __syncthreads();
+    float* dp = dpre + row * 4 * H;
+    for (int j = t; j < 4 * H; j += 256) dp[j] = dg[j];
+    for (int k = t; k < H; k += 256) {                             // dh_{prev} = W_hh^T dpre
+      float a = 0.f;
+      for (int j = 0; j < 4 * H; ++j) a = fmaf(w_hh[(size_t)j * H + k], dg[j], a);
+      dh[k] = a;
+    }
+    for (int i = t; i < I; i += 256) {                             // dx_t = W_ih^T dpre
+      float a = 0.f;
+      for (int j = 0; j < 4 * H; ++j) a = fmaf(w_ih[(size_t)j * I + i], dg[j], a);
+      dx[row * I + i] = a;
+    }
+    __syncthreads();
+  }
+}
+
+// dW_ih [4H][I], dW_hh [4H][H], db [4H] (the same for b_ih and b_hh): sums over all (t, b), rows in index order.
+__global__ __launch_bounds__(256) void k_lstm_wgrad(const float* __restrict__ dpre, const float* __restrict__ x,
+                                                   const float* __restrict__ h_all, int S, int B, int I, int H, int reverse,
+                                                   float* __restrict__ dw_ih, float* __restrict__ dw_hh, float* __restrict__ db) {
+  const int total = 4 * H * (I + H + 1);
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int j = e / (I + H + 1), c = e - j * (I + H + 1);
+    float a = 0.f;
+    for (int ts = 0; ts < S; ++ts) {
+      const int tprev = reverse ? ts + 1 : ts - 1;
+      const bool has_prev = reverse ? ts + 1 < S : ts > 0;
+      for (int b = 0; b < B; ++b) {
+        const float d = dpre[((size_t)ts * B + b) * 4 * H + j];
+        float v;
+        if (c < I) v = x[((size_t)ts * B + b) * I + c];
+        else if (c < I + H) v = has_prev ? h_all[((size_t)tprev * B + b) * H + (c - I)] : 0.f;
+        else v = 1.f;
+        a = fmaf(d, v, a);
+      }
+    }
+    if (c < I) dw_ih[(size_t)j * I + c] = a;
+    else if (c < I + H) dw_hh[(size_t)j * H + (c - I)] = a;
+    else db[j] = a;
+  }
+}
+
+extern "C" int md_lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                           int32_t S, int32_t B, int32_t I, int32_t H, int32_t reverse, float* h_all, float* c_all,
+                           float* gates, void* stream) {
+  if (!x || !w_ih || !w_hh || !b_ih || !b_hh || !h_all || !c_all || !gates) return MD_ERR_NULL;
+  if (S <= 0 || B <= 0 || I <= 0 || H <= 0) return MD_ERR_BAD_SHAPE;
+  const size_t lds = (size_t)(6 * H + I) * 4;
+  if (lds > 60000) return MD_ERR_UNSUPPORTED;
+  MD_KLAUNCH(k_lstm_fwd, dim3(B), dim3(256), lds, (hipStream_t)stream, x, w_ih, w_hh, b_ih, b_hh, S, B, I, H, reverse, h_all,
+             c_all, gates);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+extern "C" int md_lstm_bwd(const float* dh_all, const float* x, const float* w_ih, const float* w_hh, const float* h_all,
+                           const float* c_all, const float* gates, int32_t S, int32_t B, int32_t I, int32_t H, int32_t reverse,
+                           float* dx, float* dw_ih, float* dw_hh, float* db, float* dpre_scratch, void* stream) {
+  if (!dh_all || !x || !w_ih || !w_hh || !h_all || !c_all || !gates || !dx || !dw_ih || !dw_hh || !db || !dpre_scratch)
+    return MD_ERR_NULL;
+  if (S <= 0 || B <= 0 || I <= 0 || H <= 0) return MD_ERR_BAD_SHAPE;
+  const size_t lds = (size_t)(6 * H) * 4;
+  if (lds > 60000) return MD_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  MD_KLAUNCH(k_lstm_bwd, dim3(B), dim3(256), lds, s, dh_all, w_ih, w_hh, c_all, gates, S, B, I, H, reverse, dpre_scratch, dx);
+  MD_CHECK_LAUNCH();
+  const int total = 4 * H * (I + H + 1);
+  MD_KLAUNCH(k_lstm_wgrad, dim3(md_cdiv(total, 256)), dim3(256), 0, s, (const float*)dpre_scratch, x, h_all, S, B, I, H, reverse,
+             dw_ih, dw_hh, db);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}

@@ -192,3 +192,54 @@ class GlobalAvgPoolFunction(torch.autograd.Function):
         dx = torch.empty(ctx.shape, device=g.device, dtype=torch.float32)
         N.check(N.lib().md_rowmean_bwd(ops._p(g), B * Cc, thw, ops._p(dx), ops._stream()), "md_rowmean_bwd")
         return dx
+
+
+class LSTMDirectionFunction(torch.autograd.Function):
+    """One direction of one nn.LSTM layer with zero initial state: x (S,B,I) -> h (S,B,H)   (md_lstm_fwd / md_lstm_bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, reverse):
+        ops.require_cuda(x.contiguous(), w_ih, w_hh, b_ih, b_hh)
+        x = ops.f32(x).contiguous()
+        S, B, I = x.shape
+        H = w_hh.shape[1]
+        h = torch.empty((S, B, H), device=x.device, dtype=torch.float32)
+        c = torch.empty_like(h)
+        gates = torch.empty((S, B, 4 * H), device=x.device, dtype=torch.float32)
+        N.check(N.lib().md_lstm_fwd(ops._p(x), ops._p(w_ih.contiguous()), ops._p(w_hh.contiguous()), ops._p(b_ih.contiguous()),
+                                    ops._p(b_hh.contiguous()), S, B, I, H, int(bool(reverse)), ops._p(h), ops._p(c), ops._p(gates),
+                                    ops._stream()), "md_lstm_fwd")
+        ctx.save_for_backward(x, w_ih, w_hh, h, c, gates)
+        ctx.reverse = int(bool(reverse))
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        x, w_ih, w_hh, h, c, gates = ctx.saved_tensors
+        S, B, I = x.shape
+        H = w_hh.shape[1]
+        g = ops.f32(dh).contiguous()
+        dx = torch.empty_like(x)
+        dw_ih = torch.empty((4 * H, I), device=x.device); dw_hh = torch.empty((4 * H, H), device=x.device)
+        db = torch.empty(4 * H, device=x.device)
+        scratch = torch.empty(S * B * 4 * H, device=x.device)
+        N.check(N.lib().md_lstm_bwd(ops._p(g), ops._p(x), ops._p(w_ih.contiguous()), ops._p(w_hh.contiguous()), ops._p(h),
+                                    ops._p(c), ops._p(gates), S, B, I, H, ctx.reverse, ops._p(dx), ops._p(dw_ih), ops._p(dw_hh),
+                                    ops._p(db), ops._p(scratch), ops._stream()), "md_lstm_bwd")
+        return dx, dw_ih, dw_hh, db, db.clone(), None
+
+
+def lstm_forward(x, lstm: torch.nn.LSTM):
+    """nn.LSTM(batch_first=False, zero initial state, no dropout, no projection) on the gfx950 kernels: returns the output
+    sequence (S, B, num_directions*H) -- what the reference's encoders consume (CnnLSTM.py:96-97)."""
+    if lstm.batch_first or lstm.proj_size != 0 or (lstm.dropout != 0 and lstm.training) or not lstm.bias:
+        raise NotImplementedError("mi355x hot path: this nn.LSTM configuration is not used by the reference")
+    out = x
+    for layer in range(lstm.num_layers):
+        dirs = []
+        for rev in range(2 if lstm.bidirectional else 1):
+            sfx = f"_l{layer}" + ("_reverse" if rev else "")
+            dirs.append(LSTMDirectionFunction.apply(out, getattr(lstm, "weight_ih" + sfx), getattr(lstm, "weight_hh" + sfx),
+                                                    getattr(lstm, "bias_ih" + sfx), getattr(lstm, "bias_hh" + sfx), rev))
+        out = dirs[0] if len(dirs) == 1 else torch.cat(dirs, dim=2)
+    return out

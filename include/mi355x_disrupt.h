@@ -199,6 +199,17 @@ int md_maxpool_1x3x3_bwd(const float* dout, const int32_t* idx, int64_t planes, 
 int md_rowmean_fwd(const float* x, int64_t rows, int64_t thw, float* mean, void* stream);
 int md_rowmean_bwd(const float* dmean, int64_t rows, int64_t thw, float* dx, void* stream);
 
+/* One direction of one nn.LSTM layer (batch_first = False, zero initial state; gate order i, f, g, o), as used by CnnLSTM
+ * (src/models/CnnLSTM.py:51,93-96) and MLSTM_FCN.  x [S][B][I]; h_all, c_all [S][B][H]; gates [S][B][4H] (activated gates,
+ * kept for the backward); reverse != 0 processes t = S-1 .. 0 (the "_reverse" direction).  The backward takes the gradient
+ * with respect to every output h_t and returns dx, dW_ih [4H][I], dW_hh [4H][H] and db [4H] (the gradient of b_ih and of
+ * b_hh); dpre_scratch: S*B*4H floats. */
+int md_lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, int32_t S,
+                int32_t B, int32_t I, int32_t H, int32_t reverse, float* h_all, float* c_all, float* gates, void* stream);
+int md_lstm_bwd(const float* dh_all, const float* x, const float* w_ih, const float* w_hh, const float* h_all,
+                const float* c_all, const float* gates, int32_t S, int32_t B, int32_t I, int32_t H, int32_t reverse, float* dx,
+                float* dw_ih, float* dw_hh, float* db, float* dpre_scratch, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Optimizer step: torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm) + torch.optim.AdamW.step()
  * (src/train.py:64-66, train_vision_network.py:277-278) over all parameter tensors in two launches.

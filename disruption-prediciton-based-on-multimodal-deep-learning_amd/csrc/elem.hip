@@ -302,3 +302,64 @@ extern "C" int md_rowmean_bwd(const float* dmean, int64_t rows, int64_t thw, flo
   MD_CHECK_LAUNCH();
   return MD_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Small pieces of the 0D encoders (src/models/CnnLSTM.py): a per-channel bias on an (N,C,L) tensor (Conv1d bias that is NOT
+// followed directly by a normalisation, :42) and the sequence reduction that the attention pooling reduces to (:76-97).
+// ------------------------------------------------------------------------------------------------
+// MODE 0: out[n][c][l] = x[n][c][l] + bias[c];  MODE 1: out[b][d] = scale * sum_s x[b][s][d];  MODE 2: out[b][s][d] = scale * g[b][d]
+template <int MODE>
+__global__ __launch_bounds__(256) void k_small(const float* __restrict__ x, const float* __restrict__ v, float scale, int A,
+                                               int Bn, int Cn, float* __restrict__ out) {
+  const int64_t n = MODE == 1 ? (int64_t)A * Cn : (int64_t)A * Bn * Cn;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    if (MODE == 0) out[i] = x[i] + v[(i / Cn) % Bn];                       // A = N, Bn = C, Cn = L
+    else if (MODE == 1) {                                                  // A = B, Bn = S, Cn = D
+      const int64_t b = i / Cn, d = i - b * Cn;
+      float s = 0.f;
+      for (int t = 0; t < Bn; ++t) s += x[(b * Bn + t) * Cn + d];
+      out[i] = s * scale;
+    } else {                                                               // A = B, Bn = S, Cn = D: broadcast back
+      const int64_t b = i / ((int64_t)Bn * Cn), d = i % Cn;
+      out[i] = v[b * Cn + d] * scale;
+    }
+  }
+}
+// db[c] = sum over n, l of dout[n][c][l] (fixed order)
+__global__ __launch_bounds__(256) void k_channel_bias_bwd(const float* __restrict__ dout, int Nn, int Cc, int L, float* __restrict__ db) {
+  __shared__ float red[4];
+  const int c = blockIdx.x;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < Nn * L; i += 256) { const int n = i / L, l = i - n * L; s += dout[((size_t)n * Cc + c) * L + l]; }
+  const float t = block_sum256(s, red);
+  if (threadIdx.x == 0) db[c] = t;
+}
+
+extern "C" int md_channel_bias_fwd(const float* x, const float* bias, int32_t N, int32_t C, int32_t L, float* out, void* stream) {
+  if (!x || !bias || !out) return MD_ERR_NULL;
+  if (N <= 0 || C <= 0 || L <= 0) return MD_ERR_BAD_SHAPE;
+  MD_KLAUNCH(k_small<0>, dim3(elem_blocks((int64_t)N * C * L * 4)), dim3(256), 0, (hipStream_t)stream, x, bias, 1.f, N, C, L, out);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+extern "C" int md_channel_bias_bwd(const float* dout, int32_t N, int32_t C, int32_t L, float* dbias, void* stream) {
+  if (!dout || !dbias) return MD_ERR_NULL;
+  if (N <= 0 || C <= 0 || L <= 0) return MD_ERR_BAD_SHAPE;
+  MD_KLAUNCH(k_channel_bias_bwd, dim3(C), dim3(256), 0, (hipStream_t)stream, dout, N, C, L, dbias);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+extern "C" int md_seq_sum_fwd(const float* x, int32_t B, int32_t S, int32_t D, float scale, float* out, void* stream) {
+  if (!x || !out) return MD_ERR_NULL;
+  if (B <= 0 || S <= 0 || D <= 0) return MD_ERR_BAD_SHAPE;
+  MD_KLAUNCH(k_small<1>, dim3(elem_blocks((int64_t)B * D * 4)), dim3(256), 0, (hipStream_t)stream, x, (const float*)nullptr, scale, B, S, D, out);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+extern "C" int md_seq_sum_bwd(const float* dout, int32_t B, int32_t S, int32_t D, float scale, float* dx, void* stream) {
+  if (!dout || !dx) return MD_ERR_NULL;
+  if (B <= 0 || S <= 0 || D <= 0) return MD_ERR_BAD_SHAPE;
+  MD_KLAUNCH(k_small<2>, dim3(elem_blocks((int64_t)B * S * D * 4)), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, dout, scale, B, S, D, dx);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}

@@ -199,6 +199,14 @@ int md_maxpool_1x3x3_bwd(const float* dout, const int32_t* idx, int64_t planes, 
 int md_rowmean_fwd(const float* x, int64_t rows, int64_t thw, float* mean, void* stream);
 int md_rowmean_bwd(const float* dmean, int64_t rows, int64_t thw, float* dx, void* stream);
 
+/* Per-channel bias on an (N,C,L) tensor (a Conv1d bias that is not absorbed by a following normalisation,
+ * src/models/CnnLSTM.py:42) and its gradient db[c] = sum_{n,l} dout. */
+int md_channel_bias_fwd(const float* x, const float* bias, int32_t N, int32_t C, int32_t L, float* out, void* stream);
+int md_channel_bias_bwd(const float* dout, int32_t N, int32_t C, int32_t L, float* dbias, void* stream);
+/* out[b][d] = scale * sum_s x[b][s][d] and its adjoint: what CnnLSTM's attention pooling (:76-97) evaluates to -- the
+ * softmax is taken over the same axis the result is averaged over, so every step gets weight 1/H (see src/models/CnnLSTM.py). */
+int md_seq_sum_fwd(const float* x, int32_t B, int32_t S, int32_t D, float scale, float* out, void* stream);
+int md_seq_sum_bwd(const float* dout, int32_t B, int32_t S, int32_t D, float scale, float* dx, void* stream);
 /* One direction of one nn.LSTM layer (batch_first = False, zero initial state; gate order i, f, g, o), as used by CnnLSTM
  * (src/models/CnnLSTM.py:51,93-96) and MLSTM_FCN.  x [S][B][I]; h_all, c_all [S][B][H]; gates [S][B][4H] (activated gates,
  * kept for the backward); reverse != 0 processes t = S-1 .. 0 (the "_reverse" direction).  The backward takes the gradient

@@ -338,6 +338,36 @@ def gb_loops_fixture():
     print("gb loops", w, rec["dyn/weights"])
 
 
+def cnnlstm_fixture():
+    """CnnLSTM (CnnLSTM.py:10-109) of the reference (its own seeded init; noise std set to 0 so that the run is deterministic
+    without sharing the CPU generator state): state dict, input, logits, input gradient, parameter gradients, running stats."""
+    from src.models.CnnLSTM import CnnLSTM
+    torch.manual_seed(51)
+    m = CnnLSTM(seq_len=21, n_features=12, conv_dim=32, conv_kernel=3, conv_stride=1, conv_padding=1, lstm_dim=32, n_layers=2,
+                bidirectional=True, n_classes=2)
+    m.noise.std = 0.0
+    with torch.no_grad():
+        m.conv[2].weight.uniform_(0.5, 1.5); m.conv[2].bias.normal_(0, 0.3)
+        m.classifier[1].weight.uniform_(0.5, 1.5); m.classifier[1].bias.normal_(0, 0.3)
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m.train()
+    g = torch.Generator().manual_seed(52)
+    x = torch.randn(6, 21, 12, generator=g).requires_grad_(True)
+    out = m(x)
+    dout = torch.randn(out.shape, generator=g)
+    out.backward(dout)
+    rec = {"x": x.detach().numpy(), "dout": dout.numpy(), "out": out.detach().numpy(), "dx": x.grad.numpy()}
+    for k, v in sd0.items():
+        rec["sd/" + k] = v.numpy()
+    for k, p in m.named_parameters():
+        rec["grad/" + k] = p.grad.numpy()
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            rec["after/" + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "cnnlstm.npz"), **rec)
+    print("cnnlstm", out.detach().numpy()[:2], float(m.w_s1.weight.grad.abs().max()))
+
+
 if __name__ == "__main__":
     # Several seeds per configuration: LeakyReLU(0.01) makes the gradient discontinuous where a
     # pre-activation crosses zero, so two correct fp32 implementations can disagree by >1e-3 on a whole
@@ -357,3 +387,4 @@ if __name__ == "__main__":
     bottleneck_fixture("bottleneck3d_plain", 32, 8, 1, 1, 1, False, (3, 32, 3, 8, 8), 32)
     slowfast_fixture()
     gb_loops_fixture()
+    cnnlstm_fixture()

@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256) void k_row_reduce(const float* __restrict__ a,
   float s = 0.f;
   for (int64_t i = threadIdx.x; i < thw; i += 256) {
     if (MODE == 0) s += ar[i];
+    else if (MODE == 2) s += dout[row * thw + i] * ar[i];          // plain gate (no Swish): dgate = sum dout * a
     else {
       const float x = ar[i], q = x * g, sg = sigmoidf_(q);
       s += dout[row * thw + i] * (sg * (1.f + q * (1.f - sg))) * x;
@@ -153,6 +154,7 @@ __global__ __launch_bounds__(256) void k_se_gate_bwd(const float* __restrict__ d
 }
 
 // MODE 0: out = swish(a*g);  MODE 1: da = dout*swish'(a*g)*g + dpool/thw;  MODE 2: out = relu(a+b);  MODE 3: dx = dout*(out>0)
+// MODE 4: out = a*g;  MODE 5: da = dout*g + dpool/thw   (squeeze-excitation without Swish, MLSTM_FCN.py:17-33)
 template <int MODE>
 __global__ __launch_bounds__(256) void k_row_elem(const float* __restrict__ a, const float* __restrict__ b,
                                                   const float* __restrict__ rowv, const float* __restrict__ rowv2,
@@ -166,7 +168,9 @@ __global__ __launch_bounds__(256) void k_row_elem(const float* __restrict__ a, c
       r = b[i] * (sg * (1.f + q * (1.f - sg))) * g + rowv2[row] / (float)thw;
     }
     else if (MODE == 2) { const float s = a[i] + b[i]; r = s > 0.f ? s : 0.f; }
-    else r = a[i] > 0.f ? b[i] : 0.f;
+    else if (MODE == 3) r = a[i] > 0.f ? b[i] : 0.f;
+    else if (MODE == 4) r = a[i] * rowv[i / thw];
+    else { const int64_t row = i / thw; r = b[i] * rowv[row] + rowv2[row] / (float)thw; }
     out[i] = r;
   }
 }
@@ -204,6 +208,43 @@ extern "C" int md_se_swish_bwd(const float* a, const float* dout, int32_t N, int
              dpool, dw1, db1, dw2, db2);
   MD_CHECK_LAUNCH();
   MD_KLAUNCH(k_row_elem<1>, dim3(elem_blocks(n)), dim3(256), 0, s, a, dout, gate, (const float*)dpool, thw, n, da);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+// Squeeze-excitation WITHOUT the Swish (MLSTM_FCN's SqueezeExciteBlock, MLSTM_FCN.py:17-33): out = a * gate; same gate
+// network (pass zero biases for its bias-free Linears).
+extern "C" int md_se_scale_fwd(const float* a, int32_t N, int32_t Cc, int64_t thw, int32_t Wd, const float* w1, const float* b1,
+                               const float* w2, const float* b2, float* pool, float* hidden, float* gate, float* out,
+                               void* stream) {
+  if (!a || !w1 || !b1 || !w2 || !b2 || !pool || !hidden || !gate || !out) return MD_ERR_NULL;
+  if (N <= 0 || Cc <= 0 || thw <= 0 || Wd <= 0) return MD_ERR_BAD_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n = (int64_t)N * Cc * thw;
+  MD_KLAUNCH(k_row_reduce<0>, dim3(N * Cc), dim3(256), 0, s, a, (const float*)nullptr, (const float*)nullptr, thw, pool);
+  MD_CHECK_LAUNCH();
+  MD_KLAUNCH(k_se_gate_fwd, dim3(1), dim3(256), 0, s, (const float*)pool, w1, b1, w2, b2, N, Cc, Wd, hidden, gate);
+  MD_CHECK_LAUNCH();
+  MD_KLAUNCH(k_row_elem<4>, dim3(elem_blocks(n)), dim3(256), 0, s, a, (const float*)nullptr, (const float*)gate,
+             (const float*)nullptr, thw, n, out);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+extern "C" int md_se_scale_bwd(const float* a, const float* dout, int32_t N, int32_t Cc, int64_t thw, int32_t Wd,
+                               const float* w1, const float* w2, const float* pool, const float* hidden, const float* gate,
+                               float* da, float* dw1, float* db1, float* dw2, float* db2, float* scratch, void* stream) {
+  if (!a || !dout || !w1 || !w2 || !pool || !hidden || !gate || !da || !dw1 || !db1 || !dw2 || !db2 || !scratch)
+    return MD_ERR_NULL;
+  if (N <= 0 || Cc <= 0 || thw <= 0 || Wd <= 0) return MD_ERR_BAD_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n = (int64_t)N * Cc * thw;
+  float* dgate = scratch; float* dz2 = scratch + (size_t)N * Cc; float* dpool = dz2 + (size_t)N * Cc; float* dh = dpool + (size_t)N * Cc;
+  MD_KLAUNCH(k_row_reduce<2>, dim3(N * Cc), dim3(256), 0, s, a, gate, dout, thw, dgate);
+  MD_CHECK_LAUNCH();
+  MD_KLAUNCH(k_se_gate_bwd, dim3(1), dim3(256), 0, s, (const float*)dgate, gate, hidden, pool, w1, w2, N, Cc, Wd, dz2, dh,
+             dpool, dw1, db1, dw2, db2);
+  MD_CHECK_LAUNCH();
+  MD_KLAUNCH(k_row_elem<5>, dim3(elem_blocks(n)), dim3(256), 0, s, a, dout, gate, (const float*)dpool, thw, n, da);
   MD_CHECK_LAUNCH();
   return MD_OK;
 }
@@ -308,12 +349,14 @@ extern "C" int md_rowmean_bwd(const float* dmean, int64_t rows, int64_t thw, flo
 // followed directly by a normalisation, :42) and the sequence reduction that the attention pooling reduces to (:76-97).
 // ------------------------------------------------------------------------------------------------
 // MODE 0: out[n][c][l] = x[n][c][l] + bias[c];  MODE 1: out[b][d] = scale * sum_s x[b][s][d];  MODE 2: out[b][s][d] = scale * g[b][d]
+// MODE 3: out[i] = x[i] * v[i] * scale   (inverted-dropout mask between LSTM layers; A*Bn*Cn elements)
 template <int MODE>
 __global__ __launch_bounds__(256) void k_small(const float* __restrict__ x, const float* __restrict__ v, float scale, int A,
                                                int Bn, int Cn, float* __restrict__ out) {
   const int64_t n = MODE == 1 ? (int64_t)A * Cn : (int64_t)A * Bn * Cn;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    if (MODE == 0) out[i] = x[i] + v[(i / Cn) % Bn];                       // A = N, Bn = C, Cn = L
+    if (MODE == 3) out[i] = x[i] * v[i] * scale;
+    else if (MODE == 0) out[i] = x[i] + v[(i / Cn) % Bn];                  // A = N, Bn = C, Cn = L
     else if (MODE == 1) {                                                  // A = B, Bn = S, Cn = D
       const int64_t b = i / Cn, d = i - b * Cn;
       float s = 0.f;
@@ -360,6 +403,14 @@ extern "C" int md_seq_sum_bwd(const float* dout, int32_t B, int32_t S, int32_t D
   if (!dout || !dx) return MD_ERR_NULL;
   if (B <= 0 || S <= 0 || D <= 0) return MD_ERR_BAD_SHAPE;
   MD_KLAUNCH(k_small<2>, dim3(elem_blocks((int64_t)B * S * D * 4)), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, dout, scale, B, S, D, dx);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+extern "C" int md_mask_scale(const float* x, const float* mask, float scale, int64_t n, float* out, void* stream) {
+  if (!x || !mask || !out) return MD_ERR_NULL;
+  if (n <= 0 || n > 0x7fffffff) return MD_ERR_BAD_SHAPE;
+  MD_KLAUNCH(k_small<3>, dim3(elem_blocks(n * 4)), dim3(256), 0, (hipStream_t)stream, x, mask, scale, (int)n, 1, 1, out);
   MD_CHECK_LAUNCH();
   return MD_OK;
 }

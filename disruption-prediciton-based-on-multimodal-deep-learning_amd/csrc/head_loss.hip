@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ feat
     for (int b = 0; b < B; ++b) {
       const float xh = (h0[b * Hd + j] - mean) * is;
       const float y = xh * gamma[j] + beta[j];
-      const float z = y > 0.f ? y : alpha * expm1f(y);
+      const float z = y > 0.f ? y : (alpha >= 0.f ? alpha * expm1f(y) : -alpha * y);       // ELU(alpha) | LeakyReLU(-alpha)
       xhat[b * Hd + j] = xh; hn[b * Hd + j] = y; hes[b * Hd + j] = z; he[b * Hd + j] = z;
     }
   }
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void k_head_bwd(const float* __restrict__ dlog
     const int b = e / Hd, j = e - b * Hd;
     float a = 0.f; for (int k = 0; k < K; ++k) a = fmaf(dlogits[b * K + k], w1[k * Hd + j], a);
     const float y = hn[e];
-    dh[e] = a * (y > 0.f ? 1.f : alpha * expf(y));     // ELU'
+    dh[e] = a * (y > 0.f ? 1.f : (alpha >= 0.f ? alpha * expf(y) : -alpha));     // ELU' | LeakyReLU'
   }
   __syncthreads();
   for (int j = t; j < Hd; j += nt) {

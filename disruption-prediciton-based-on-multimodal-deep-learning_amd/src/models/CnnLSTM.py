@@ -18,58 +18,8 @@ import torch.nn as nn
 from .. import _native as N
 from .. import ops
 from .NoiseLayer import NoiseLayer
-from ._unit import ConvBnLeakyFunction, ConvFunction, HeadFunction, lstm_forward
-
-
-class _ChannelBias(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, bias):                      # x (N, C, L)
-        x = ops.f32(x).contiguous()
-        out = torch.empty_like(x)
-        Nn, Cc, L = x.shape
-        N.check(N.lib().md_channel_bias_fwd(ops._p(x), ops._p(bias.contiguous()), Nn, Cc, L, ops._p(out), ops._stream()),
-                "md_channel_bias_fwd")
-        ctx.shape = (Nn, Cc, L)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        Nn, Cc, L = ctx.shape
-        g = ops.f32(dout).contiguous()
-        db = torch.empty(Cc, device=g.device)
-        N.check(N.lib().md_channel_bias_bwd(ops._p(g), Nn, Cc, L, ops._p(db), ops._stream()), "md_channel_bias_bwd")
-        return g, db
-
-
-class _SeqSum(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, scale, *zero_grad_params):   # x (B, S, D) -> (B, D); the extra parameters get exact zero gradients
-        x = ops.f32(x).contiguous()
-        B, S, D = x.shape
-        out = torch.empty((B, D), device=x.device)
-        N.check(N.lib().md_seq_sum_fwd(ops._p(x), B, S, D, float(scale), ops._p(out), ops._stream()), "md_seq_sum_fwd")
-        ctx.shape = (B, S, D); ctx.scale = float(scale)
-        ctx.zshapes = [tuple(p.shape) for p in zero_grad_params]
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        B, S, D = ctx.shape
-        g = ops.f32(dout).contiguous()
-        dx = torch.empty((B, S, D), device=g.device)
-        N.check(N.lib().md_seq_sum_bwd(ops._p(g), B, S, D, ctx.scale, ops._p(dx), ops._stream()), "md_seq_sum_bwd")
-        return (dx, None) + tuple(torch.zeros(s, device=g.device) for s in ctx.zshapes)
-
-
-class _AbsorbedBias(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, out, bias):
-        ctx.n = bias.numel()
-        return out.view_as(out)
-
-    @staticmethod
-    def backward(ctx, dout):
-        return dout, torch.zeros(ctx.n, device=dout.device, dtype=dout.dtype)
+from ._unit import (ConvBnLeakyFunction, ConvFunction, HeadFunction, lstm_forward, _AbsorbedBias, _ChannelBias,
+                    _SeqSum)
 
 
 class CnnLSTM(nn.Module):

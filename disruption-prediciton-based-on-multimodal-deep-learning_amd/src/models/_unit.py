@@ -232,10 +232,16 @@ class LSTMDirectionFunction(torch.autograd.Function):
 def lstm_forward(x, lstm: torch.nn.LSTM):
     """nn.LSTM(batch_first=False, zero initial state, no dropout, no projection) on the gfx950 kernels: returns the output
     sequence (S, B, num_directions*H) -- what the reference's encoders consume (CnnLSTM.py:96-97)."""
-    if lstm.batch_first or lstm.proj_size != 0 or (lstm.dropout != 0 and lstm.training) or not lstm.bias:
+    if lstm.batch_first or lstm.proj_size != 0 or not lstm.bias:
         raise NotImplementedError("mi355x hot path: this nn.LSTM configuration is not used by the reference")
     out = x
     for layer in range(lstm.num_layers):
+        if layer > 0 and lstm.dropout > 0 and lstm.training:
+            # nn.LSTM's inter-layer dropout: mask drawn with torch's device generator (no bit-compatibility with MIOpen's
+            # internal dropout state is possible; the distribution is the same), applied by md_mask_scale
+            keep = 1.0 - lstm.dropout
+            mask = torch.empty_like(out).bernoulli_(keep)
+            out = _MaskScale.apply(out, mask, 1.0 / keep)
         dirs = []
         for rev in range(2 if lstm.bidirectional else 1):
             sfx = f"_l{layer}" + ("_reverse" if rev else "")
@@ -243,3 +249,103 @@ def lstm_forward(x, lstm: torch.nn.LSTM):
                                                     getattr(lstm, "bias_ih" + sfx), getattr(lstm, "bias_hh" + sfx), rev))
         out = dirs[0] if len(dirs) == 1 else torch.cat(dirs, dim=2)
     return out
+
+
+class _ChannelBias(torch.autograd.Function):
+    """x (N, C, L) + bias[c]   (md_channel_bias_*)."""
+    @staticmethod
+    def forward(ctx, x, bias):                      # x (N, C, L)
+        x = ops.f32(x).contiguous()
+        out = torch.empty_like(x)
+        Nn, Cc, L = x.shape
+        N.check(N.lib().md_channel_bias_fwd(ops._p(x), ops._p(bias.contiguous()), Nn, Cc, L, ops._p(out), ops._stream()),
+                "md_channel_bias_fwd")
+        ctx.shape = (Nn, Cc, L)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        Nn, Cc, L = ctx.shape
+        g = ops.f32(dout).contiguous()
+        db = torch.empty(Cc, device=g.device)
+        N.check(N.lib().md_channel_bias_bwd(ops._p(g), Nn, Cc, L, ops._p(db), ops._stream()), "md_channel_bias_bwd")
+        return g, db
+
+
+class _SeqSum(torch.autograd.Function):
+    """scale * sum over the sequence axis of x (B, S, D)   (md_seq_sum_*): the closed form of the reference's attention
+    pooling (see models/CnnLSTM.py); extra parameters passed in get exact zero gradients."""
+    @staticmethod
+    def forward(ctx, x, scale, *zero_grad_params):   # x (B, S, D) -> (B, D); the extra parameters get exact zero gradients
+        x = ops.f32(x).contiguous()
+        B, S, D = x.shape
+        out = torch.empty((B, D), device=x.device)
+        N.check(N.lib().md_seq_sum_fwd(ops._p(x), B, S, D, float(scale), ops._p(out), ops._stream()), "md_seq_sum_fwd")
+        ctx.shape = (B, S, D); ctx.scale = float(scale)
+        ctx.zshapes = [tuple(p.shape) for p in zero_grad_params]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, S, D = ctx.shape
+        g = ops.f32(dout).contiguous()
+        dx = torch.empty((B, S, D), device=g.device)
+        N.check(N.lib().md_seq_sum_bwd(ops._p(g), B, S, D, ctx.scale, ops._p(dx), ops._stream()), "md_seq_sum_bwd")
+        return (dx, None) + tuple(torch.zeros(s, device=g.device) for s in ctx.zshapes)
+
+
+class _AbsorbedBias(torch.autograd.Function):
+    """A convolution / linear bias in front of a training-mode BatchNorm cancels in the output; its gradient is exactly zero."""
+    @staticmethod
+    def forward(ctx, out, bias):
+        ctx.n = bias.numel()
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, dout):
+        return dout, torch.zeros(ctx.n, device=dout.device, dtype=dout.dtype)
+
+
+class _MaskScale(torch.autograd.Function):
+    """x * mask * scale (inverted dropout with a given mask; md_mask_scale)."""
+
+    @staticmethod
+    def forward(ctx, x, mask, scale):
+        x = ops.f32(x).contiguous()
+        out = torch.empty_like(x)
+        N.check(N.lib().md_mask_scale(ops._p(x), ops._p(mask), float(scale), x.numel(), ops._p(out), ops._stream()), "md_mask_scale")
+        ctx.save_for_backward(mask); ctx.scale = float(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (mask,) = ctx.saved_tensors
+        g = ops.f32(dout).contiguous()
+        dx = torch.empty_like(g)
+        N.check(N.lib().md_mask_scale(ops._p(g), ops._p(mask), ctx.scale, g.numel(), ops._p(dx), ops._stream()), "md_mask_scale")
+        return dx, None, None
+
+
+def conv1d_bn_leaky(x_bct, conv: torch.nn.Conv1d, bn: torch.nn.BatchNorm1d, slope: float, training: bool):
+    """Conv1d (with or without bias) -> BatchNorm1d -> LeakyReLU(slope) on (B, C, T) as a (k,1,1) unit of the conv kernels;
+    a bias only shifts the batch mean, so it is folded into the running mean (state dicts stay interchangeable with the
+    reference) and gets its exact zero gradient."""
+    x5 = x_bct.contiguous()[:, :, :, None, None]
+    w5 = conv.weight[:, :, :, None, None]
+    b = None if conv.bias is None else conv.bias.detach()
+    rmean = bn.running_mean if (training or b is None) else bn.running_mean - b
+    z = ConvBnLeakyFunction.apply(x5, w5, bn.weight, bn.bias, rmean, bn.running_var, (conv.stride[0], 1, 1), (conv.padding[0], 0, 0),
+                                  float(slope), bool(training), float(bn.eps), float(bn.momentum))
+    if training:
+        if b is not None:
+            bn.running_mean.add_(b * bn.momentum)
+            z = _AbsorbedBias.apply(z, conv.bias)
+        bn.num_batches_tracked += 1
+    return z[:, :, :, 0, 0]
+
+
+def linear(x, lin: torch.nn.Linear):
+    """nn.Linear on (B, D) rows as a 1x1x1 convolution plus the per-channel bias kernel."""
+    y = ConvFunction.apply(x.contiguous()[:, :, None, None, None], lin.weight[:, :, None, None, None], (1, 1, 1), (0, 0, 0))
+    y = y[:, :, 0, 0, 0]
+    return y if lin.bias is None else _ChannelBias.apply(y[:, :, None], lin.bias)[:, :, 0]

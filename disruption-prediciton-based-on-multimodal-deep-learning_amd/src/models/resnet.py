@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from .. import _native as N
 from .. import ops
-from ._unit import conv_bn_leaky
+from ._unit import _AbsorbedBias, conv_bn_leaky
 
 
 class SwishEfficient(torch.autograd.Function):
@@ -168,19 +168,6 @@ class Bottleneck3D(nn.Module):
         out = conv_bn_leaky(out, self.conv3, self.bn3, 1.0, self.training)     # conv3 -> bn3
         residual = x if self.downsample is None else self._downsample(x)
         return _AddReluFunction.apply(out, residual)
-
-
-class _AbsorbedBias(torch.autograd.Function):
-    """A convolution bias in front of a training-mode BatchNorm cancels in the output; its gradient is exactly zero."""
-
-    @staticmethod
-    def forward(ctx, out, bias):
-        ctx.n = bias.numel()
-        return out.view_as(out)
-
-    @staticmethod
-    def backward(ctx, dout):
-        return dout, torch.zeros(ctx.n, device=dout.device, dtype=dout.dtype)
 
 
 def _conv_bias_bn_relu(x, conv: nn.Conv3d, bn: nn.BatchNorm3d, training: bool):

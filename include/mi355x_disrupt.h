@@ -150,8 +150,9 @@ int md_cl_to_nchw(const float* x, int32_t B, int32_t C, int64_t thw, float* out,
 int md_avgpool_fwd(const float* x, int32_t B, int32_t C, int64_t thw, float* feat, void* stream);
 int md_avgpool_bwd(const float* dfeat, int32_t B, int32_t C, int64_t thw, float* dx, void* stream);
 
-/* Classifier head Linear(D->Hd) + BatchNorm1d(Hd) + ELU(alpha) + Linear(Hd->K), R2Plus1D.py:243-248.
- * save: workspace of md_head_save_floats() floats kept for backward. */
+/* Classifier head Linear(D->Hd) + BatchNorm1d(Hd) + activation + Linear(Hd->K), R2Plus1D.py:243-248 (the same shape of
+ * head closes SlowFast, CnnLSTM and MLSTM_FCN).  Activation: alpha >= 0 -> ELU(alpha) (alpha = 0 is ReLU);
+ * alpha < 0 -> LeakyReLU(-alpha) (MLSTM_FCN.py:117).  save: workspace of md_head_save_floats() floats kept for backward. */
 size_t md_head_save_floats(int32_t B, int32_t D, int32_t Hd);
 int md_head_fwd(const float* feat, int32_t B, int32_t D, int32_t Hd, int32_t K,
                 const float* w0, const float* b0, const float* gamma, const float* beta,
@@ -187,6 +188,15 @@ int md_se_swish_fwd(const float* a, int32_t N, int32_t C, int64_t thw, int32_t W
 int md_se_swish_bwd(const float* a, const float* dout, int32_t N, int32_t C, int64_t thw, int32_t Wd, const float* w1,
                     const float* w2, const float* pool, const float* hidden, const float* gate, float* da, float* dw1,
                     float* db1, float* dw2, float* db2, float* scratch, void* stream);
+/* Squeeze-excitation without the Swish (MLSTM_FCN's SqueezeExciteBlock on (N,C,T), MLSTM_FCN.py:17-33): out = a * gate, same
+ * gate network and buffers as md_se_swish_* (its Linears have no bias: pass zero vectors). */
+int md_se_scale_fwd(const float* a, int32_t N, int32_t C, int64_t thw, int32_t Wd, const float* w1, const float* b1,
+                    const float* w2, const float* b2, float* pool, float* hidden, float* gate, float* out, void* stream);
+int md_se_scale_bwd(const float* a, const float* dout, int32_t N, int32_t C, int64_t thw, int32_t Wd, const float* w1,
+                    const float* w2, const float* pool, const float* hidden, const float* gate, float* da, float* dw1,
+                    float* db1, float* dw2, float* db2, float* scratch, void* stream);
+/* out = x * mask * scale: the inverted-dropout mask nn.LSTM applies between its layers in training mode. */
+int md_mask_scale(const float* x, const float* mask, float scale, int64_t n, float* out, void* stream);
 /* Residual close of Bottleneck3D (resnet.py:196-198): out = relu(a + b); dx = dout * (out > 0) for both inputs. */
 int md_add_relu_fwd(const float* a, const float* b, int64_t n, float* out, void* stream);
 int md_add_relu_bwd(const float* out, const float* dout, int64_t n, float* dx, void* stream);

@@ -368,6 +368,37 @@ def cnnlstm_fixture():
     print("cnnlstm", out.detach().numpy()[:2], float(m.w_s1.weight.grad.abs().max()))
 
 
+def mlstm_fcn_fixture():
+    """MLSTM_FCN (MLSTM_FCN.py:84-169) of the reference (its own seeded init; noise std and LSTM dropout 0 for determinism):
+    state dict, input, logits, input gradient, parameter gradients, running statistics."""
+    from src.models.MLSTM_FCN import MLSTM_FCN
+    torch.manual_seed(61)
+    m = MLSTM_FCN(n_features=14, fcn_dim=32, kernel_size=3, stride=1, seq_len=21, lstm_dim=24, lstm_n_layers=2,
+                  lstm_bidirectional=True, lstm_dropout=0.0, reduction=16, alpha=0.01, n_classes=2)
+    m.noise.std = 0.0
+    with torch.no_grad():
+        for k, v in m.named_parameters():
+            if ".bn." in k or k.startswith("classifier.1."):
+                (v.uniform_(0.5, 1.5) if k.endswith("weight") else v.normal_(0, 0.3))
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m.train()
+    g = torch.Generator().manual_seed(62)
+    x = torch.randn(8, 21, 14, generator=g).requires_grad_(True)
+    out = m(x)
+    dout = torch.randn(out.shape, generator=g)
+    out.backward(dout)
+    rec = {"x": x.detach().numpy(), "dout": dout.numpy(), "out": out.detach().numpy(), "dx": x.grad.numpy()}
+    for k, v in sd0.items():
+        rec["sd/" + k] = v.numpy()
+    for k, p in m.named_parameters():
+        rec["grad/" + k] = p.grad.numpy()
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            rec["after/" + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "mlstm_fcn.npz"), **rec)
+    print("mlstm_fcn", out.detach().numpy()[:2])
+
+
 if __name__ == "__main__":
     # Several seeds per configuration: LeakyReLU(0.01) makes the gradient discontinuous where a
     # pre-activation crosses zero, so two correct fp32 implementations can disagree by >1e-3 on a whole
@@ -388,3 +419,4 @@ if __name__ == "__main__":
     slowfast_fixture()
     gb_loops_fixture()
     cnnlstm_fixture()
+    mlstm_fcn_fixture()

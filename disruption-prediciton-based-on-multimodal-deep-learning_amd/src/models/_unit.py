@@ -349,3 +349,97 @@ def linear(x, lin: torch.nn.Linear):
     y = ConvFunction.apply(x.contiguous()[:, :, None, None, None], lin.weight[:, :, None, None, None], (1, 1, 1), (0, 0, 0))
     y = y[:, :, 0, 0, 0]
     return y if lin.bias is None else _ChannelBias.apply(y[:, :, None], lin.bias)[:, :, 0]
+
+
+class AddLayerNormFunction(torch.autograd.Function):
+    """LayerNorm(a + b) over the last dimension (b may be None)   (md_add_layernorm_*)."""
+
+    @staticmethod
+    def forward(ctx, a, b, gamma, beta, eps):
+        a = ops.f32(a).contiguous()
+        ops.require_cuda(a, gamma, beta)
+        D = a.shape[-1]
+        rows = a.numel() // D
+        bb = None if b is None else ops.f32(b).contiguous()
+        out = torch.empty_like(a); xhat = torch.empty_like(a); rstd = torch.empty(rows, device=a.device)
+        N.check(N.lib().md_add_layernorm_fwd(ops._p(a), ops._p(bb), ops._p(gamma.contiguous()), ops._p(beta.contiguous()), rows, D,
+                                             float(eps), ops._p(out), ops._p(xhat), ops._p(rstd), ops._stream()), "md_add_layernorm_fwd")
+        ctx.save_for_backward(gamma, xhat, rstd)
+        ctx.has_b = b is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        gamma, xhat, rstd = ctx.saved_tensors
+        g = ops.f32(dout).contiguous()
+        D = g.shape[-1]
+        rows = g.numel() // D
+        dx = torch.empty_like(g); dgamma = torch.empty(D, device=g.device); dbeta = torch.empty(D, device=g.device)
+        N.check(N.lib().md_add_layernorm_bwd(ops._p(g), ops._p(gamma.contiguous()), ops._p(xhat), ops._p(rstd), rows, D, ops._p(dx),
+                                             ops._p(dgamma), ops._p(dbeta), ops._stream()), "md_add_layernorm_bwd")
+        return dx, (dx if ctx.has_b else None), dgamma, dbeta, None
+
+
+class AttentionFunction(torch.autograd.Function):
+    """softmax(q k^T / sqrt(dh) + mask) [* dropout] v per head on qkv (S, B, 3D) -> (S, B, D)   (md_attention_*)."""
+
+    @staticmethod
+    def forward(ctx, qkv, mask, heads, drop):
+        qkv = ops.f32(qkv).contiguous()
+        ops.require_cuda(qkv, mask, drop)
+        S, B, D3 = qkv.shape
+        D = D3 // 3
+        probs = torch.empty((B * heads, S, S), device=qkv.device); out = torch.empty((S, B, D), device=qkv.device)
+        N.check(N.lib().md_attention_fwd(ops._p(qkv), ops._p(mask), ops._p(drop), S, B, D, int(heads), ops._p(probs), ops._p(out),
+                                         ops._stream()), "md_attention_fwd")
+        ctx.save_for_backward(qkv, probs, drop) if drop is not None else ctx.save_for_backward(qkv, probs)
+        ctx.heads = int(heads); ctx.has_drop = drop is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if ctx.has_drop:
+            qkv, probs, drop = ctx.saved_tensors
+        else:
+            (qkv, probs), drop = ctx.saved_tensors, None
+        S, B, D3 = qkv.shape
+        g = ops.f32(dout).contiguous()
+        dqkv = torch.empty_like(qkv)
+        N.check(N.lib().md_attention_bwd(ops._p(qkv), ops._p(probs), ops._p(drop), ops._p(g), S, B, D3 // 3, ctx.heads, ops._p(dqkv),
+                                         ops._stream()), "md_attention_bwd")
+        return dqkv, None, None, None
+
+
+class GeluFunction(torch.autograd.Function):
+    """kind 0: nn.GELU (erf); kind 1: the reference's tanh form (transformer.py:35-37)   (md_gelu)."""
+
+    @staticmethod
+    def forward(ctx, x, kind):
+        x = ops.f32(x).contiguous()
+        ops.require_cuda(x)
+        out = torch.empty_like(x)
+        N.check(N.lib().md_gelu(ops._p(x), None, int(kind), x.numel(), ops._p(out), ops._stream()), "md_gelu")
+        ctx.save_for_backward(x); ctx.kind = int(kind)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x,) = ctx.saved_tensors
+        g = ops.f32(dout).contiguous()
+        dx = torch.empty_like(x)
+        N.check(N.lib().md_gelu(ops._p(x), ops._p(g), ctx.kind, x.numel(), ops._p(dx), ops._stream()), "md_gelu")
+        return dx, None
+
+
+def linear_wb(x2d, weight, bias):
+    """x (rows, D_in) @ weight(D_out, D_in)^T + bias as a 1x1x1 convolution plus the per-channel bias kernel."""
+    y = ConvFunction.apply(x2d.contiguous()[:, :, None, None, None], weight[:, :, None, None, None], (1, 1, 1), (0, 0, 0))[:, :, 0, 0, 0]
+    return y if bias is None else _ChannelBias.apply(y[:, :, None], bias)[:, :, 0]
+
+
+def dropout(x, p: float, training: bool):
+    """Inverted dropout with a mask from torch's device generator, applied by md_mask_scale."""
+    if not training or p <= 0.0:
+        return x
+    keep = 1.0 - p
+    return _MaskScale.apply(x, torch.empty_like(x).bernoulli_(keep), 1.0 / keep)

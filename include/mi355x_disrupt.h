@@ -217,6 +217,23 @@ int md_channel_bias_bwd(const float* dout, int32_t N, int32_t C, int32_t L, floa
  * softmax is taken over the same axis the result is averaged over, so every step gets weight 1/H (see src/models/CnnLSTM.py). */
 int md_seq_sum_fwd(const float* x, int32_t B, int32_t S, int32_t D, float scale, float* out, void* stream);
 int md_seq_sum_bwd(const float* dout, int32_t B, int32_t S, int32_t D, float scale, float* dx, void* stream);
+/* Pieces of the Transformer 0D encoder (src/models/transformer.py:40-109 over nn.TransformerEncoderLayer, post-norm):
+ *  - out = LayerNorm(a + b) * gamma + beta per row of D features (b may be NULL); xhat [rows][D] and rstd [rows] are kept for
+ *    the backward, whose dx is the gradient of BOTH summands.
+ *  - attention core of nn.MultiheadAttention: qkv [S][B][3D] (q | k | v), H heads, additive mask [S][S] (may be NULL, -inf
+ *    allowed), drop [B*H][S][S] = keep-mask / keep-probability of the attention dropout (may be NULL); probs [B*H][S][S] are
+ *    kept for the backward; out [S][B][D].
+ *  - GELU: kind 0 = exact erf form (nn.GELU, transformer.py:85), kind 1 = the reference's tanh form (:35-37); with dy != NULL
+ *    the call returns dy * gelu'(x). */
+int md_add_layernorm_fwd(const float* a, const float* b, const float* gamma, const float* beta, int64_t rows, int32_t D, float eps,
+                         float* out, float* xhat, float* rstd, void* stream);
+int md_add_layernorm_bwd(const float* dout, const float* gamma, const float* xhat, const float* rstd, int64_t rows, int32_t D,
+                         float* dx, float* dgamma, float* dbeta, void* stream);
+int md_attention_fwd(const float* qkv, const float* mask, const float* drop, int32_t S, int32_t B, int32_t D, int32_t H, float* probs,
+                     float* out, void* stream);
+int md_attention_bwd(const float* qkv, const float* probs, const float* drop, const float* dout, int32_t S, int32_t B, int32_t D,
+                     int32_t H, float* dqkv, void* stream);
+int md_gelu(const float* x, const float* dy, int32_t kind, int64_t n, float* out, void* stream);
 /* One direction of one nn.LSTM layer (batch_first = False, zero initial state; gate order i, f, g, o), as used by CnnLSTM
  * (src/models/CnnLSTM.py:51,93-96) and MLSTM_FCN.  x [S][B][I]; h_all, c_all [S][B][H]; gates [S][B][4H] (activated gates,
  * kept for the backward); reverse != 0 processes t = S-1 .. 0 (the "_reverse" direction).  The backward takes the gradient

@@ -399,6 +399,37 @@ def mlstm_fcn_fixture():
     print("mlstm_fcn", out.detach().numpy()[:2])
 
 
+def transformer0d_fixture():
+    """Transformer (transformer.py:112-154) of the reference (its own seeded init; noise std and dropout 0 for determinism): state
+    dict, input, logits, input gradient, parameter gradients, running statistics."""
+    from src.models.transformer import Transformer
+    torch.manual_seed(71)
+    m = Transformer(n_features=18, kernel_size=5, feature_dims=64, max_len=21, n_layers=2, n_heads=4, dim_feedforward=96, dropout=0.0,
+                    cls_dims=32, n_classes=2)
+    m.encoder.noise.std = 0.0
+    with torch.no_grad():
+        for k, v in m.named_parameters():
+            if "norm" in k or "filter.2" in k or k.endswith("connector.1.weight") or k.endswith("connector.1.bias") or k.startswith("classifier.1"):
+                (v.uniform_(0.5, 1.5) if k.endswith("weight") else v.normal_(0, 0.3))
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m.train()
+    g = torch.Generator().manual_seed(72)
+    x = torch.randn(8, 21, 18, generator=g).requires_grad_(True)
+    out = m(x)
+    dout = torch.randn(out.shape, generator=g)
+    out.backward(dout)
+    rec = {"x": x.detach().numpy(), "dout": dout.numpy(), "out": out.detach().numpy(), "dx": x.grad.numpy()}
+    for k, v in sd0.items():
+        rec["sd/" + k] = v.numpy()
+    for k, p in m.named_parameters():
+        rec["grad/" + k] = p.grad.numpy()
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            rec["after/" + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "transformer0d.npz"), **rec)
+    print("transformer0d", out.detach().numpy()[:2])
+
+
 if __name__ == "__main__":
     # Several seeds per configuration: LeakyReLU(0.01) makes the gradient discontinuous where a
     # pre-activation crosses zero, so two correct fp32 implementations can disagree by >1e-3 on a whole
@@ -420,3 +451,4 @@ if __name__ == "__main__":
     gb_loops_fixture()
     cnnlstm_fixture()
     mlstm_fcn_fixture()
+    transformer0d_fixture()

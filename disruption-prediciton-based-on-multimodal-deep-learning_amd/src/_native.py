@@ -95,10 +95,12 @@ SIGNATURES = {
     "md_channel_bias_bwd": (C.c_int, [_P, _I32, _I32, _I32, _P, _P]),
     "md_seq_sum_fwd": (C.c_int, [_P, _I32, _I32, _I32, _F, _P, _P]),
     "md_seq_sum_bwd": (C.c_int, [_P, _I32, _I32, _I32, _F, _P, _P]),
-    "md_add_layernorm_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int64, _I32, _F, _P, _P, _P, _P]),
-    "md_add_layernorm_bwd": (C.c_int, [_P, _P, _P, _P, C.c_int64, _I32, _P, _P, _P, _P]),
-    "md_attention_fwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P]),
-    "md_attention_bwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P]),
+    "md_add_layernorm_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int64, _I32, _F, _P, _P, _P, _P, _P]),
+    "md_add_layernorm_bwd_scratch_floats": (_SZ, [C.c_int64, _I32]),
+    "md_add_layernorm_bwd": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _I32, _P, _P, _P, _P, _P]),
+    "md_attention_fwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
+    "md_attention_bwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
+    "md_elu": (C.c_int, [_P, _P, _F, C.c_int64, _P, _P]),
     "md_gelu": (C.c_int, [_P, _P, _I32, C.c_int64, _P, _P]),
     "md_lstm_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P]),
     "md_lstm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P]),

@@ -351,6 +351,18 @@ def linear(x, lin: torch.nn.Linear):
     return y if lin.bias is None else _ChannelBias.apply(y[:, :, None], lin.bias)[:, :, 0]
 
 
+def _ln_backward(g, gamma, xhat, rstd, dres):
+    D = g.shape[-1]
+    rows = g.numel() // D
+    dx = torch.empty_like(g); dgamma = torch.empty(D, device=g.device); dbeta = torch.empty(D, device=g.device)
+    ns = N.lib().md_add_layernorm_bwd_scratch_floats(rows, D)
+    scratch = torch.empty(ns, device=g.device) if ns else None
+    N.check(N.lib().md_add_layernorm_bwd(ops._p(g), ops._p(gamma.contiguous()), ops._p(xhat), ops._p(rstd), ops._p(dres), rows, D,
+                                         ops._p(dx), ops._p(dgamma), ops._p(dbeta), ops._p(scratch), ops._stream()),
+            "md_add_layernorm_bwd")
+    return dx, dgamma, dbeta
+
+
 class AddLayerNormFunction(torch.autograd.Function):
     """LayerNorm(a + b) over the last dimension (b may be None)   (md_add_layernorm_*)."""
 
@@ -363,7 +375,8 @@ class AddLayerNormFunction(torch.autograd.Function):
         bb = None if b is None else ops.f32(b).contiguous()
         out = torch.empty_like(a); xhat = torch.empty_like(a); rstd = torch.empty(rows, device=a.device)
         N.check(N.lib().md_add_layernorm_fwd(ops._p(a), ops._p(bb), ops._p(gamma.contiguous()), ops._p(beta.contiguous()), rows, D,
-                                             float(eps), ops._p(out), ops._p(xhat), ops._p(rstd), ops._stream()), "md_add_layernorm_fwd")
+                                             float(eps), ops._p(out), ops._p(xhat), ops._p(rstd), None, ops._stream()),
+                "md_add_layernorm_fwd")
         ctx.save_for_backward(gamma, xhat, rstd)
         ctx.has_b = b is not None
         return out
@@ -371,29 +384,53 @@ class AddLayerNormFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         gamma, xhat, rstd = ctx.saved_tensors
-        g = ops.f32(dout).contiguous()
-        D = g.shape[-1]
-        rows = g.numel() // D
-        dx = torch.empty_like(g); dgamma = torch.empty(D, device=g.device); dbeta = torch.empty(D, device=g.device)
-        N.check(N.lib().md_add_layernorm_bwd(ops._p(g), ops._p(gamma.contiguous()), ops._p(xhat), ops._p(rstd), rows, D, ops._p(dx),
-                                             ops._p(dgamma), ops._p(dbeta), ops._stream()), "md_add_layernorm_bwd")
+        dx, dgamma, dbeta = _ln_backward(ops.f32(dout).contiguous(), gamma, xhat, rstd, None)
         return dx, (dx if ctx.has_b else None), dgamma, dbeta, None
 
 
-class AttentionFunction(torch.autograd.Function):
-    """softmax(q k^T / sqrt(dh) + mask) [* dropout] v per head on qkv (S, B, 3D) -> (S, B, D)   (md_attention_*)."""
+class ResidualLayerNormFunction(torch.autograd.Function):
+    """(s, h) = (a + b, LayerNorm(a + b)): one step of a pre-norm residual stream (reference ViViT.py:108-111).  The backward adds
+    the gradient that arrives through s to the LayerNorm's, so the stream never fans out in autograd."""
 
     @staticmethod
-    def forward(ctx, qkv, mask, heads, drop):
+    def forward(ctx, a, b, gamma, beta, eps):
+        a = ops.f32(a).contiguous(); b = ops.f32(b).contiguous()
+        ops.require_cuda(a, b, gamma, beta)
+        ctx.set_materialize_grads(False)
+        D = a.shape[-1]
+        rows = a.numel() // D
+        out = torch.empty_like(a); xhat = torch.empty_like(a); rstd = torch.empty(rows, device=a.device); s = torch.empty_like(a)
+        N.check(N.lib().md_add_layernorm_fwd(ops._p(a), ops._p(b), ops._p(gamma.contiguous()), ops._p(beta.contiguous()), rows, D,
+                                             float(eps), ops._p(out), ops._p(xhat), ops._p(rstd), ops._p(s), ops._stream()),
+                "md_add_layernorm_fwd")
+        ctx.save_for_backward(gamma, xhat, rstd)
+        return s, out
+
+    @staticmethod
+    def backward(ctx, ds, dout):
+        gamma, xhat, rstd = ctx.saved_tensors
+        if dout is None:                                  # the normalised branch was not used: identity for the stream
+            return ds, ds, torch.zeros_like(gamma), torch.zeros_like(gamma), None
+        dres = None if ds is None else ops.f32(ds).contiguous()
+        dx, dgamma, dbeta = _ln_backward(ops.f32(dout).contiguous(), gamma, xhat, rstd, dres)
+        return dx, dx, dgamma, dbeta, None
+
+
+class AttentionFunction(torch.autograd.Function):
+    """softmax(q k^T / sqrt(dh) + mask) [* dropout] v per head   (md_attention_*).  qkv (S, B, 3D) -> (S, B, D), or with
+    batch_first (B, S, 3D) -> (B, S, D)."""
+
+    @staticmethod
+    def forward(ctx, qkv, mask, heads, drop, batch_first=False):
         qkv = ops.f32(qkv).contiguous()
         ops.require_cuda(qkv, mask, drop)
-        S, B, D3 = qkv.shape
+        (B, S, D3) = qkv.shape if batch_first else (qkv.shape[1], qkv.shape[0], qkv.shape[2])
         D = D3 // 3
-        probs = torch.empty((B * heads, S, S), device=qkv.device); out = torch.empty((S, B, D), device=qkv.device)
-        N.check(N.lib().md_attention_fwd(ops._p(qkv), ops._p(mask), ops._p(drop), S, B, D, int(heads), ops._p(probs), ops._p(out),
-                                         ops._stream()), "md_attention_fwd")
+        probs = torch.empty((B * heads, S, S), device=qkv.device); out = torch.empty(qkv.shape[:2] + (D,), device=qkv.device)
+        N.check(N.lib().md_attention_fwd(ops._p(qkv), ops._p(mask), ops._p(drop), S, B, D, int(heads), int(batch_first), ops._p(probs),
+                                         ops._p(out), ops._stream()), "md_attention_fwd")
         ctx.save_for_backward(qkv, probs, drop) if drop is not None else ctx.save_for_backward(qkv, probs)
-        ctx.heads = int(heads); ctx.has_drop = drop is not None
+        ctx.heads = int(heads); ctx.has_drop = drop is not None; ctx.bf = bool(batch_first)
         return out
 
     @staticmethod
@@ -402,12 +439,65 @@ class AttentionFunction(torch.autograd.Function):
             qkv, probs, drop = ctx.saved_tensors
         else:
             (qkv, probs), drop = ctx.saved_tensors, None
-        S, B, D3 = qkv.shape
+        (B, S, D3) = qkv.shape if ctx.bf else (qkv.shape[1], qkv.shape[0], qkv.shape[2])
         g = ops.f32(dout).contiguous()
         dqkv = torch.empty_like(qkv)
-        N.check(N.lib().md_attention_bwd(ops._p(qkv), ops._p(probs), ops._p(drop), ops._p(g), S, B, D3 // 3, ctx.heads, ops._p(dqkv),
-                                         ops._stream()), "md_attention_bwd")
-        return dqkv, None, None, None
+        scratch = torch.empty_like(probs)
+        N.check(N.lib().md_attention_bwd(ops._p(qkv), ops._p(probs), ops._p(drop), ops._p(g), S, B, D3 // 3, ctx.heads, int(ctx.bf),
+                                         ops._p(dqkv), ops._p(scratch), ops._stream()), "md_attention_bwd")
+        return dqkv, None, None, None, None
+
+
+class EluFunction(torch.autograd.Function):
+    """nn.ELU(alpha)   (md_elu)."""
+
+    @staticmethod
+    def forward(ctx, x, alpha):
+        x = ops.f32(x).contiguous()
+        ops.require_cuda(x)
+        out = torch.empty_like(x)
+        N.check(N.lib().md_elu(ops._p(x), None, float(alpha), x.numel(), ops._p(out), ops._stream()), "md_elu")
+        ctx.save_for_backward(x); ctx.alpha = float(alpha)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        N.check(N.lib().md_elu(ops._p(x), ops._p(ops.f32(dout).contiguous()), ctx.alpha, x.numel(), ops._p(dx), ops._stream()), "md_elu")
+        return dx, None
+
+
+class LinearRowsFunction(torch.autograd.Function):
+    """x (rows, Din) @ w (Dout, Din)^T with the rows laid along the W axis of one 1x1x1 convolution (row-major rows ARE the
+    channels-last layout), so 128-row tiles go through the MFMA kernels however many rows there are."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        x = ops.f32(x).contiguous(); w = ops.f32(w).contiguous()
+        ops.require_cuda(x, w)
+        rows, Din = x.shape
+        Dout = w.shape[0]
+        d = ops.make_desc(1, 1, 1, rows, Din, Dout, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+        if Din % 4:
+            x = torch.nn.functional.pad(x, (0, ops.cpad(Din) - Din))
+        wf, wd = ops.pack_weights(d, w[:, :, None, None, None].contiguous(), want_dgrad=True)
+        y, _ = ops.conv_fwd(d, ops.view(x), wf, x.device, want_stats=False)
+        ctx.d = d
+        ctx.save_for_backward(x, wd)
+        return y.view(rows, ops.cpad(Dout))[:, :Dout]
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, wd = ctx.saved_tensors
+        d = ctx.d
+        dy = ops.f32(dout)
+        if d.Cout % 4:
+            dy = torch.nn.functional.pad(dy, (0, ops.cpad(d.Cout) - d.Cout))
+        dy = dy.contiguous()
+        dw = ops.conv_wgrad(d, ops.view(x), dy).view(d.Cout, d.Cin)
+        dx = ops.conv_dgrad(d, dy, wd).view(-1, ops.cpad(d.Cin))[:, :d.Cin] if ctx.needs_input_grad[0] else None
+        return dx, dw
 
 
 class GeluFunction(torch.autograd.Function):
@@ -432,9 +522,9 @@ class GeluFunction(torch.autograd.Function):
 
 
 def linear_wb(x2d, weight, bias):
-    """x (rows, D_in) @ weight(D_out, D_in)^T + bias as a 1x1x1 convolution plus the per-channel bias kernel."""
-    y = ConvFunction.apply(x2d.contiguous()[:, :, None, None, None], weight[:, :, None, None, None], (1, 1, 1), (0, 0, 0))[:, :, 0, 0, 0]
-    return y if bias is None else _ChannelBias.apply(y[:, :, None], bias)[:, :, 0]
+    """x (rows, D_in) @ weight(D_out, D_in)^T + bias: the rows-major 1x1x1 convolution plus the per-channel bias kernel."""
+    y = LinearRowsFunction.apply(x2d, weight)
+    return y if bias is None else _ChannelBias.apply(y.contiguous()[:, :, None], bias)[:, :, 0]
 
 
 def dropout(x, p: float, training: bool):

@@ -226,13 +226,21 @@ int md_seq_sum_bwd(const float* dout, int32_t B, int32_t S, int32_t D, float sca
  *  - GELU: kind 0 = exact erf form (nn.GELU, transformer.py:85), kind 1 = the reference's tanh form (:35-37); with dy != NULL
  *    the call returns dy * gelu'(x). */
 int md_add_layernorm_fwd(const float* a, const float* b, const float* gamma, const float* beta, int64_t rows, int32_t D, float eps,
-                         float* out, float* xhat, float* rstd, void* stream);
-int md_add_layernorm_bwd(const float* dout, const float* gamma, const float* xhat, const float* rstd, int64_t rows, int32_t D,
-                         float* dx, float* dgamma, float* dbeta, void* stream);
-int md_attention_fwd(const float* qkv, const float* mask, const float* drop, int32_t S, int32_t B, int32_t D, int32_t H, float* probs,
-                     float* out, void* stream);
+                         float* out, float* xhat, float* rstd, float* sum_out /* may be NULL: a + b, the pre-norm residual stream
+                         of ViViT's Transformer (src/models/ViViT.py:108-111) */, void* stream);
+size_t md_add_layernorm_bwd_scratch_floats(int64_t rows, int32_t D);
+/* dres (may be NULL): gradient that reached a + b through the residual stream, added to dx.  scratch: as sized above (may be
+ * NULL when that is 0). */
+int md_add_layernorm_bwd(const float* dout, const float* gamma, const float* xhat, const float* rstd, const float* dres,
+                         int64_t rows, int32_t D, float* dx, float* dgamma, float* dbeta, float* scratch, void* stream);
+/* batch_first = 0: qkv [S][B][3D], out [S][B][D] (nn.MultiheadAttention); 1: qkv [B][S][3D], out [B][S][D] (ViViT's Attention,
+ * src/models/ViViT.py:69-88: 'b n (h d)' heads, scale d_head^-0.5, no mask).  S*16*4 bytes of LDS: S <= 937. */
+int md_attention_fwd(const float* qkv, const float* mask, const float* drop, int32_t S, int32_t B, int32_t D, int32_t H,
+                     int32_t batch_first, float* probs, float* out, void* stream);
 int md_attention_bwd(const float* qkv, const float* probs, const float* drop, const float* dout, int32_t S, int32_t B, int32_t D,
-                     int32_t H, float* dqkv, void* stream);
+                     int32_t H, int32_t batch_first, float* dqkv, float* ds_scratch /* B*H*S*S floats */, void* stream);
+/* ELU (src/models/ViViT.py:166): with dy != NULL the call returns dy * elu'(x). */
+int md_elu(const float* x, const float* dy, float alpha, int64_t n, float* out, void* stream);
 int md_gelu(const float* x, const float* dy, int32_t kind, int64_t n, float* out, void* stream);
 /* One direction of one nn.LSTM layer (batch_first = False, zero initial state; gate order i, f, g, o), as used by CnnLSTM
  * (src/models/CnnLSTM.py:51,93-96) and MLSTM_FCN.  x [S][B][I]; h_all, c_all [S][B][H]; gates [S][B][4H] (activated gates,

@@ -430,6 +430,35 @@ def transformer0d_fixture():
     print("transformer0d", out.detach().numpy()[:2])
 
 
+def vivit_fixture():
+    """ViViT (pool cls, with mlp) and ViViTEncoder (pool mean) of the reference (ViViT.py:115-299; its own seeded init with the
+    LayerNorm parameters moved off 1/0; dropout 0): state dict, clip, output, input gradient, parameter gradients."""
+    from src.models.ViViT import ViViT, ViViTEncoder
+    rec = {}
+    for tag, cls, kw, seed in (("cls", ViViT, dict(n_classes=2, pool="cls", alpha=0.7), 81), ("enc", ViViTEncoder, dict(pool="mean"), 83)):
+        torch.manual_seed(seed)
+        m = cls(image_size=32, patch_size=8, n_frames=5, dim=32, depth=2, n_heads=2, in_channels=3, d_head=16, dropout=0.0,
+                embedd_dropout=0.0, scale_dim=2, **kw)
+        with torch.no_grad():
+            for k, v in m.named_parameters():
+                if "norm" in k or k.startswith("mlp.1"):
+                    (v.uniform_(0.5, 1.5) if k.endswith("weight") else v.normal_(0, 0.3))
+        m.train()
+        g = torch.Generator().manual_seed(seed + 1)
+        x = torch.randn(3, 5, 3, 32, 32, generator=g).requires_grad_(True)           # (b, t, c, H, W)
+        out = m(x)
+        dout = torch.randn(out.shape, generator=g)
+        out.backward(dout)
+        rec.update({tag + "/x": x.detach().numpy(), tag + "/dout": dout.numpy(), tag + "/out": out.detach().numpy(),
+                    tag + "/dx": x.grad.numpy()})
+        for k, v in m.state_dict().items():
+            rec[tag + "/sd/" + k] = v.detach().numpy()
+        for k, p in m.named_parameters():
+            rec[tag + "/grad/" + k] = p.grad.numpy()
+        print("vivit", tag, out.detach().numpy().ravel()[:4])
+    np.savez_compressed(os.path.join(HERE, "vivit.npz"), **rec)
+
+
 if __name__ == "__main__":
     # Several seeds per configuration: LeakyReLU(0.01) makes the gradient discontinuous where a
     # pre-activation crosses zero, so two correct fp32 implementations can disagree by >1e-3 on a whole
@@ -452,3 +481,4 @@ if __name__ == "__main__":
     cnnlstm_fixture()
     mlstm_fcn_fixture()
     transformer0d_fixture()
+    vivit_fixture()

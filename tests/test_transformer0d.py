@@ -76,11 +76,17 @@ def test_native_module_matches_reference_fixture(golden_dir, exact):
 
 @pytest.mark.gpu
 def test_attention_layernorm_gelu_ops_match_torch():
-    from src.models._unit import AddLayerNormFunction, AttentionFunction, GeluFunction
     torch.manual_seed(5)
-    S, B, D, H = 21, 3, 32, 4
+    for S, B, D, H, masked in ((21, 3, 32, 4, True), (197, 2, 48, 3, False)):     # the 0D encoder's sequence; ViViT's 196+1 tokens
+        _check_attention(S, B, D, H, masked)
+    _check_ln_gelu()
+
+
+def _check_attention(S, B, D, H, masked):
+    from src.models._unit import AttentionFunction
     dh = D // H
-    qkv = torch.randn(S, B, 3 * D); mask = torch.triu(torch.full((S, S), float("-inf")), diagonal=1)
+    qkv = torch.randn(S, B, 3 * D)
+    mask = torch.triu(torch.full((S, S), float("-inf")), diagonal=1) if masked else torch.zeros(S, S)
     drop = (torch.rand(B * H, S, S) > 0.2).float() / 0.8
     qr = qkv.clone().requires_grad_(True)
     q, k, v = qr.chunk(3, dim=2)
@@ -94,6 +100,14 @@ def test_attention_layernorm_gelu_ops_match_torch():
     out.backward(dout.cuda())
     assert float((out.detach().cpu() - ref.detach()).abs().max()) < 2e-6
     assert float((qg.grad.cpu() - qr.grad).abs().max()) < 2e-5
+    if not masked:
+        qg2 = qkv.cuda().requires_grad_(True)
+        out2 = AttentionFunction.apply(qg2, None, H, drop.cuda()); out2.backward(dout.cuda())
+        assert torch.equal(out2, out) and torch.equal(qg2.grad, qg.grad)
+
+
+def _check_ln_gelu():
+    from src.models._unit import AddLayerNormFunction, GeluFunction
     # residual add + LayerNorm
     a = torch.randn(40, 96); b = torch.randn(40, 96); ga = torch.rand(96) + 0.5; be = torch.randn(96)
     ar, br, gr, ber = (t.clone().requires_grad_(True) for t in (a, b, ga, be))

@@ -1,0 +1,113 @@
+"""Scope rows a9-a11: ViViT / ViViTEncoder (src/models/ViViT.py:12-299).
+CPU: the oracle restatement (einops patterns written out) against the fixture recorded from the reference (2e-5).
+GPU: the native modules against the same fixture: outputs within 1e-3 of their scale, input and parameter gradients within 3e-3
+relative L2 (both arithmetic modes); the BASELINE cfg3 shape (4,3,21,224,224) runs forward + backward with finite results and
+the documented shapes; ELU and the residual-stream LayerNorm against PyTorch on the CPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import vivit as ov
+
+BASE = dict(image_size=32, patch_size=8, n_frames=5, dim=32, depth=2, n_heads=2, in_channels=3, d_head=16, dropout=0.0,
+            embedd_dropout=0.0, scale_dim=2)
+CASES = {"cls": ("ViViT", dict(n_classes=2, pool="cls", alpha=0.7)), "enc": ("ViViTEncoder", dict(pool="mean"))}
+
+
+def _load(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, "vivit.npz"))
+    pre = tag + "/sd/"
+    return g, {k[len(pre):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre)}
+
+
+@pytest.mark.parametrize("tag", ["cls", "enc"])
+def test_oracle_matches_reference_fixture(golden_dir, tag):
+    g, sd = _load(golden_dir, tag)
+    kw = CASES[tag][1]
+    out = ov.vivit_forward(torch.from_numpy(g[tag + "/x"]), sd, 8, 2, 2, kw["pool"], 3, kw.get("alpha", 1.0), with_mlp=(tag == "cls"))
+    ref = torch.from_numpy(g[tag + "/out"])
+    assert float((out - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def _relerr(a, b):
+    return float((a.double() - b.double()).norm() / max(1e-12, float(b.double().norm())))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exact", [True, False], ids=["exact_fp32", "split"])
+@pytest.mark.parametrize("tag", ["cls", "enc"])
+def test_native_module_matches_reference_fixture(golden_dir, tag, exact):
+    from src import ops
+    from src.models import ViViT as V
+    g, sd = _load(golden_dir, tag)
+    name, kw = CASES[tag]
+    m = getattr(V, name)(**BASE, **kw)
+    m.load_state_dict(sd, strict=True)
+    m.cuda().train()
+    x = torch.from_numpy(g[tag + "/x"]).cuda().requires_grad_(True)
+    ops.set_exact_fp32(exact)
+    try:
+        out = m(x)
+        out.backward(torch.from_numpy(g[tag + "/dout"]).cuda())
+        torch.cuda.synchronize()
+    finally:
+        ops.set_exact_fp32(False)
+    ref = torch.from_numpy(g[tag + "/out"])
+    assert float((out.detach().cpu() - ref).abs().max()) <= 1e-3 * max(1.0, float(ref.abs().max()))
+    assert _relerr(x.grad.cpu(), torch.from_numpy(g[tag + "/dx"])) < 3e-3
+    for k, p in m.named_parameters():
+        r = torch.from_numpy(g[tag + "/grad/" + k])
+        assert p.grad is not None, k
+        assert _relerr(p.grad.cpu(), r) < 3e-3, (k, _relerr(p.grad.cpu(), r))
+    # the channels-first clip layout is accepted as well (ViViT.py:174-175) and encode() is the forward without the mlp
+    m.eval()
+    with torch.no_grad():
+        x5 = x.detach()
+        a = m(x5); b = m(x5.permute(0, 2, 1, 3, 4).contiguous())
+        assert torch.equal(a, b)
+        if tag == "cls":
+            assert tuple(m.encode(x5).shape) == (3, 32)
+
+
+@pytest.mark.gpu
+def test_baseline_cfg3_shape_runs():
+    """BASELINE.json configs[2]: (B=4, T=21, 3, 224, 224), patch 16, dim 128, depth 2, heads 4, d_head 64, scale_dim 8, pool mean."""
+    from src.models.ViViT import ViViT
+    torch.manual_seed(0)
+    m = ViViT(image_size=224, patch_size=16, n_frames=21, n_classes=2, dim=128, depth=2, n_heads=4, pool="mean", in_channels=3,
+              d_head=64, dropout=0.1, embedd_dropout=0.1, scale_dim=8).cuda().train()
+    x = torch.randn(4, 3, 21, 224, 224, device="cuda")
+    out = m(x)
+    assert tuple(out.shape) == (4, 2)
+    out.sum().backward()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out).all())
+    for k, p in m.named_parameters():
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
+    assert float(m.space_transformer.layers[0][0].fn.to_qkv.weight.grad.abs().max()) > 0
+
+
+@pytest.mark.gpu
+def test_elu_and_residual_layernorm_match_torch():
+    from src.models._unit import EluFunction, ResidualLayerNormFunction
+    torch.manual_seed(9)
+    x = torch.linspace(-8, 8, 2001)
+    for alpha in (1.0, 0.7):
+        xr = x.clone().requires_grad_(True); yr = F.elu(xr, alpha); yr.backward(torch.ones_like(x))
+        xg = x.cuda().requires_grad_(True); yg = EluFunction.apply(xg, alpha); yg.backward(torch.ones_like(xg))
+        assert float((yg.detach().cpu() - yr.detach()).abs().max()) < 2e-6 and float((xg.grad.cpu() - xr.grad).abs().max()) < 2e-6
+    for rows in (40, 3000):                                   # single-pass and chunked parameter-gradient reductions
+        a = torch.randn(rows, 96); b = torch.randn(rows, 96); ga = torch.rand(96) + 0.5; be = torch.randn(96)
+        ds = torch.randn(rows, 96); dh = torch.randn(rows, 96)
+        ar, br, gr, ber = (t.clone().requires_grad_(True) for t in (a, b, ga, be))
+        s = ar + br; h = F.layer_norm(s, (96,), gr, ber, 1e-5)
+        torch.autograd.backward((s, h), (ds, dh))
+        ag, bg, gg, beg = (t.cuda().requires_grad_(True) for t in (a, b, ga, be))
+        s2, h2 = ResidualLayerNormFunction.apply(ag, bg, gg, beg, 1e-5)
+        torch.autograd.backward((s2, h2), (ds.cuda(), dh.cuda()))
+        for x_, y_ in ((s2.detach(), s.detach()), (h2.detach(), h.detach()), (ag.grad, ar.grad), (bg.grad, br.grad), (gg.grad, gr.grad),
+                       (beg.grad, ber.grad)):
+            assert float((x_.cpu() - y_).abs().max()) < 3e-5 * max(1.0, float(y_.abs().max()))

@@ -216,8 +216,51 @@ __global__ __launch_bounds__(256) void k_elu(const float* __restrict__ x, const 
                                             float* __restrict__ out) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float v = x[i], e = alpha * expf(fminf(v, 0.f));
-    out[i] = dy ? dy[i] * (v > 0.f ? 1.f : e) : (v > 0.f ? v : e - alpha);
+    const bool pos = !(v <= 0.f);                       // NaN stays NaN, as in ATen
+    out[i] = dy ? dy[i] * (pos ? 1.f : e) : (pos ? v : e - alpha);
   }
+}
+// Tensor-fusion outer product (MultiModal.py:216-220): with A = [1 | a[b]] (Da+1) and C = [1 | c[b]] (Dc+1),
+// out[b][i][j] = A_i * C_j.  bwd: da[b][i-1] = sum_j dout[b][i][j] C_j;  dc[b][j-1] = sum_i dout[b][i][j] A_i  (fixed order).
+__global__ __launch_bounds__(256) void k_outer_fwd(const float* __restrict__ a, const float* __restrict__ c, int B, int Da, int Dc,
+                                                  float* __restrict__ out) {
+  const int64_t n = (int64_t)B * (Da + 1) * (Dc + 1);
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const int j = (int)(e % (Dc + 1)); const int64_t r = e / (Dc + 1);
+    const int i = (int)(r % (Da + 1)), b = (int)(r / (Da + 1));
+    out[e] = (i ? a[(size_t)b * Da + i - 1] : 1.f) * (j ? c[(size_t)b * Dc + j - 1] : 1.f);
+  }
+}
+__global__ __launch_bounds__(256) void k_outer_bwd(const float* __restrict__ a, const float* __restrict__ c, const float* __restrict__ dout,
+                                                  int Da, int Dc, float* __restrict__ da, float* __restrict__ dc) {
+  const int b = blockIdx.x;
+  const float* g = dout + (size_t)b * (Da + 1) * (Dc + 1);
+  for (int i = 1 + threadIdx.x; i <= Da; i += 256) {
+    float s = g[(size_t)i * (Dc + 1)];
+    for (int j = 1; j <= Dc; ++j) s = fmaf(g[(size_t)i * (Dc + 1) + j], c[(size_t)b * Dc + j - 1], s);
+    da[(size_t)b * Da + i - 1] = s;
+  }
+  for (int j = 1 + threadIdx.x; j <= Dc; j += 256) {
+    float s = g[j];
+    for (int i = 1; i <= Da; ++i) s = fmaf(g[(size_t)i * (Dc + 1) + j], a[(size_t)b * Da + i - 1], s);
+    dc[(size_t)b * Dc + j - 1] = s;
+  }
+}
+extern "C" int md_outer_fwd(const float* a, const float* c, int32_t B, int32_t Da, int32_t Dc, float* out, void* stream) {
+  if (!a || !c || !out) return MD_ERR_NULL;
+  if (B <= 0 || Da <= 0 || Dc <= 0) return MD_ERR_BAD_SHAPE;
+  int64_t blocks = ((int64_t)B * (Da + 1) * (Dc + 1) + 255) / 256; if (blocks > 8192) blocks = 8192;
+  MD_KLAUNCH(k_outer_fwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, c, B, Da, Dc, out);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+extern "C" int md_outer_bwd(const float* a, const float* c, const float* dout, int32_t B, int32_t Da, int32_t Dc, float* da, float* dc,
+                            void* stream) {
+  if (!a || !c || !dout || !da || !dc) return MD_ERR_NULL;
+  if (B <= 0 || Da <= 0 || Dc <= 0) return MD_ERR_BAD_SHAPE;
+  MD_KLAUNCH(k_outer_bwd, dim3(B), dim3(256), 0, (hipStream_t)stream, a, c, dout, Da, Dc, da, dc);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
 }
 extern "C" int md_elu(const float* x, const float* dy, float alpha, int64_t n, float* out, void* stream) {
   if (!x || !out) return MD_ERR_NULL;

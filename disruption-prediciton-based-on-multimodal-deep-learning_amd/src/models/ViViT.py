@@ -70,8 +70,8 @@ class FeedForward(nn.Module):
 
     def forward(self, x: torch.Tensor):
         h = GeluFunction.apply(_rows(x, self.net[0]), 0)
-        h = dropout(h, self.net[2].p, self.training)
-        return dropout(_rows(h, self.net[3]), self.net[4].p, self.training)
+        h = dropout(h, self.net[2].p, self.net[2].training)
+        return dropout(_rows(h, self.net[3]), self.net[4].p, self.net[4].training)
 
 
 class Attention(nn.Module):
@@ -99,7 +99,7 @@ class Attention(nn.Module):
         out = AttentionFunction.apply(_rows(x, self.to_qkv), None, self.n_heads, None, True)
         if isinstance(self.to_out, nn.Identity):
             return out
-        return dropout(_rows(out, self.to_out[0]), self.to_out[1].p, self.training)
+        return dropout(_rows(out, self.to_out[0]), self.to_out[1].p, self.to_out[1].training)
 
 
 class Transformer(nn.Module):
@@ -184,7 +184,7 @@ class _ViViTBase(nn.Module):
         if pos.shape[0] != t:
             raise RuntimeError("ViViT: the clip has %d frames, the positional table %d" % (t, pos.shape[0]))
         x = _ChannelBias.apply(x.reshape(b, t * (n + 1) * d, 1), pos.reshape(-1)).reshape(b * t, n + 1, d)
-        x = dropout(x, self.dropout.p, self.training)
+        x = dropout(x, self.dropout.p, self.dropout.training)
         x = self.space_transformer(x)
         x = x[:, 0].reshape(b, t, d)
         x = _with_token(x, self.temporal_token)                                     # (b, t+1, d)
@@ -211,10 +211,12 @@ class ViViT(_ViViTBase):
             nn.Linear(dim // 2, n_classes)
         )
 
-    def forward(self, x: torch.Tensor):
-        x = self._encode(x)
-        x = _layer_norm(_rows(x, self.mlp[0]), self.mlp[1])
+    def _head(self, latent: torch.Tensor):
+        x = _layer_norm(_rows(latent, self.mlp[0]), self.mlp[1])
         return _rows(EluFunction.apply(x, self.mlp[2].alpha), self.mlp[3])
+
+    def forward(self, x: torch.Tensor):
+        return self._head(self._encode(x))
 
     def encode(self, x: torch.Tensor):
         with torch.no_grad():

@@ -326,22 +326,56 @@ class _MaskScale(torch.autograd.Function):
         return dx, None, None
 
 
+def _unit_with_bias(x5, w5, bias, bn, stride, padding, slope: float, training: bool):
+    b = None if bias is None else bias.detach()
+    rmean = bn.running_mean if (training or b is None) else bn.running_mean - b
+    z = ConvBnLeakyFunction.apply(x5, w5, bn.weight, bn.bias, rmean, bn.running_var, stride, padding, float(slope), bool(training),
+                                  float(bn.eps), float(bn.momentum))
+    if training:
+        if b is not None:
+            bn.running_mean.add_(b * bn.momentum)
+            z = _AbsorbedBias.apply(z, bias)
+        bn.num_batches_tracked += 1
+    return z
+
+
 def conv1d_bn_leaky(x_bct, conv: torch.nn.Conv1d, bn: torch.nn.BatchNorm1d, slope: float, training: bool):
     """Conv1d (with or without bias) -> BatchNorm1d -> LeakyReLU(slope) on (B, C, T) as a (k,1,1) unit of the conv kernels;
     a bias only shifts the batch mean, so it is folded into the running mean (state dicts stay interchangeable with the
     reference) and gets its exact zero gradient."""
-    x5 = x_bct.contiguous()[:, :, :, None, None]
-    w5 = conv.weight[:, :, :, None, None]
-    b = None if conv.bias is None else conv.bias.detach()
-    rmean = bn.running_mean if (training or b is None) else bn.running_mean - b
-    z = ConvBnLeakyFunction.apply(x5, w5, bn.weight, bn.bias, rmean, bn.running_var, (conv.stride[0], 1, 1), (conv.padding[0], 0, 0),
-                                  float(slope), bool(training), float(bn.eps), float(bn.momentum))
-    if training:
-        if b is not None:
-            bn.running_mean.add_(b * bn.momentum)
-            z = _AbsorbedBias.apply(z, conv.bias)
-        bn.num_batches_tracked += 1
+    z = _unit_with_bias(x_bct.contiguous()[:, :, :, None, None], conv.weight[:, :, :, None, None], conv.bias, bn,
+                        (conv.stride[0], 1, 1), (conv.padding[0], 0, 0), slope, training)
     return z[:, :, :, 0, 0]
+
+
+def linear_bn_leaky(x, lin: torch.nn.Linear, bn: torch.nn.BatchNorm1d, slope: float, training: bool):
+    """Linear -> BatchNorm1d -> LeakyReLU(slope) (slope 0 = ReLU) on (B, D) rows: the same unit with a 1x1x1 kernel."""
+    z = _unit_with_bias(x.contiguous()[:, :, None, None, None], lin.weight[:, :, None, None, None], lin.bias, bn, (1, 1, 1), (0, 0, 0),
+                        slope, training)
+    return z[:, :, 0, 0, 0]
+
+
+class OuterFusionFunction(torch.autograd.Function):
+    """[1 | a] (x) [1 | c] per sample, flattened: (B, Da), (B, Dc) -> (B, (Da+1)(Dc+1))   (md_outer_*)."""
+
+    @staticmethod
+    def forward(ctx, a, c):
+        a = ops.f32(a).contiguous(); c = ops.f32(c).contiguous()
+        ops.require_cuda(a, c)
+        B, Da = a.shape
+        Dc = c.shape[1]
+        out = torch.empty((B, (Da + 1) * (Dc + 1)), device=a.device)
+        N.check(N.lib().md_outer_fwd(ops._p(a), ops._p(c), B, Da, Dc, ops._p(out), ops._stream()), "md_outer_fwd")
+        ctx.save_for_backward(a, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, c = ctx.saved_tensors
+        da = torch.empty_like(a); dc = torch.empty_like(c)
+        N.check(N.lib().md_outer_bwd(ops._p(a), ops._p(c), ops._p(ops.f32(dout).contiguous()), a.shape[0], a.shape[1], c.shape[1],
+                                     ops._p(da), ops._p(dc), ops._stream()), "md_outer_bwd")
+        return da, dc
 
 
 def linear(x, lin: torch.nn.Linear):

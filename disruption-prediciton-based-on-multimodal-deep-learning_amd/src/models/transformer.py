@@ -144,11 +144,19 @@ class Transformer(nn.Module):
         with torch.no_grad():
             return self.encoder(x)
 
-    def forward(self, x: torch.Tensor):
-        x = self.encoder(x)
+    @property
+    def feature_dims(self):
+        # the reference's MultiModalModel_GB / TFN_GB read this attribute (MultiModal.py:65,259), which its Transformer never
+        # sets; exposed here so those classes construct
+        return self.encoder.feature_dims
+
+    def _head(self, latent: torch.Tensor):
         lin0, ln, lin1 = self.classifier[0], self.classifier[1], self.classifier[3]
-        h = AddLayerNormFunction.apply(linear(x, lin0), None, ln.weight, ln.bias, ln.eps)
+        h = AddLayerNormFunction.apply(linear(latent, lin0), None, ln.weight, ln.bias, ln.eps)
         return linear(GeluFunction.apply(h, 1), lin1)
+
+    def forward(self, x: torch.Tensor):
+        return self._head(self.encoder(x))
 
     def summary(self):
         self.encoder.summary()

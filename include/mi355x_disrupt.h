@@ -239,9 +239,14 @@ int md_attention_fwd(const float* qkv, const float* mask, const float* drop, int
                      int32_t batch_first, float* probs, float* out, void* stream);
 int md_attention_bwd(const float* qkv, const float* probs, const float* drop, const float* dout, int32_t S, int32_t B, int32_t D,
                      int32_t H, int32_t batch_first, float* dqkv, float* ds_scratch /* B*H*S*S floats */, void* stream);
-/* ELU (src/models/ViViT.py:166): with dy != NULL the call returns dy * elu'(x). */
+/* ELU (src/models/ViViT.py:166): with dy != NULL the call returns dy * elu'(x).  alpha = 0 is ReLU (MultiModal.py:23,29). */
 int md_elu(const float* x, const float* dy, float alpha, int64_t n, float* out, void* stream);
 int md_gelu(const float* x, const float* dy, int32_t kind, int64_t n, float* out, void* stream);
+/* Tensor fusion of TFN / TFN_GB (src/models/MultiModal.py:214-220, 301-307): out [B][(Da+1)*(Dc+1)] = [1 | a[b]] (x) [1 | c[b]]
+ * (what the reference builds with torch.cat of ones + torch.bmm); the backward returns da [B][Da], dc [B][Dc]. */
+int md_outer_fwd(const float* a, const float* c, int32_t B, int32_t Da, int32_t Dc, float* out, void* stream);
+int md_outer_bwd(const float* a, const float* c, const float* dout, int32_t B, int32_t Da, int32_t Dc, float* da, float* dc,
+                 void* stream);
 /* One direction of one nn.LSTM layer (batch_first = False, zero initial state; gate order i, f, g, o), as used by CnnLSTM
  * (src/models/CnnLSTM.py:51,93-96) and MLSTM_FCN.  x [S][B][I]; h_all, c_all [S][B][H]; gates [S][B][4H] (activated gates,
  * kept for the backward); reverse != 0 processes t = S-1 .. 0 (the "_reverse" direction).  The backward takes the gradient

@@ -38,8 +38,10 @@ def transformer0d_forward(x, sd, n_layers: int, n_heads: int, kernel_size: int, 
     z = h.permute(1, 0, 2).mean(dim=1)                                                                    # :103
     z = F.gelu(F.layer_norm(F.linear(z, sd[e + "connector.0.weight"], sd[e + "connector.0.bias"]), (D,), sd[e + "connector.1.weight"],
                             sd[e + "connector.1.bias"], 1e-5))                                            # :83-87
-    if not with_classifier:
-        return z
+    return classifier_head(z, sd) if with_classifier else z
+
+
+def classifier_head(z, sd):                                                                               # :132-137
     c = F.linear(z, sd["classifier.0.weight"], sd["classifier.0.bias"])
     c = _gelu_tanh(F.layer_norm(c, (c.shape[1],), sd["classifier.1.weight"], sd["classifier.1.bias"], 1e-5))
-    return F.linear(c, sd["classifier.3.weight"], sd["classifier.3.bias"])                               # :132-137
+    return F.linear(c, sd["classifier.3.weight"], sd["classifier.3.bias"])

@@ -45,8 +45,10 @@ def vivit_forward(x, sd, patch_size, depth, n_heads, pool, in_channels=3, alpha=
     x = torch.cat((sd["temporal_token"].reshape(1, 1, d).expand(b, 1, d), x), dim=1)                 # :190
     x = _transformer(x, sd, "temporal_transformer.", depth, n_heads)
     x = x.mean(dim=1) if pool == "mean" else x[:, 0]                                                 # :192
-    if not with_mlp:
-        return x
-    h = F.linear(x, sd["mlp.0.weight"], sd["mlp.0.bias"])                                            # :163-168
+    return vivit_head(x, sd, alpha) if with_mlp else x
+
+
+def vivit_head(latent, sd, alpha=1.0):                                                               # :163-168
+    h = F.linear(latent, sd["mlp.0.weight"], sd["mlp.0.bias"])
     h = F.elu(F.layer_norm(h, (h.shape[1],), sd["mlp.1.weight"], sd["mlp.1.bias"], 1e-5), alpha)
     return F.linear(h, sd["mlp.3.weight"], sd["mlp.3.bias"])

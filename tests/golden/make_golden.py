@@ -459,6 +459,54 @@ def vivit_fixture():
     np.savez_compressed(os.path.join(HERE, "vivit.npz"), **rec)
 
 
+def multimodal_fixture():
+    """The four fusion wrappers of the reference (MultiModal.py:10-331) on tiny encoders (noise std 0, dropout 0; LayerNorm /
+    BatchNorm parameters moved off 1/0): state dict, inputs, outputs, parameter gradients of sum_k <out_k, dout_k>, running
+    statistics afterwards.  The *_GB classes need Transformer.feature_dims, which the reference never sets: the
+    attribute is supplied on the imported class, nothing else is touched."""
+    from src.models import MultiModal as MM
+    from src.models.transformer import Transformer
+    Transformer.feature_dims = property(lambda self: self.encoder.feature_dims)
+    av = dict(image_size=32, patch_size=8, n_frames=5, dim=16, depth=1, n_heads=2, in_channels=3, d_head=8, dropout=0.0,
+              embedd_dropout=0.0, scale_dim=2)
+    a0 = dict(n_features=6, kernel_size=3, feature_dims=16, max_len=5, n_layers=1, n_heads=2, dim_feedforward=24, dropout=0.0)
+    avg = dict(av, n_classes=2, pool="cls", alpha=1.0)
+    a0g = dict(a0, cls_dims=12, n_classes=2)
+    rec = {}
+    for tag, cls, v, z, seed in (("mm", MM.MultiModalModel, dict(av, pool="mean"), a0, 91), ("gb", MM.MultiModalModel_GB, avg, a0g, 92),
+                                 ("tfn", MM.TFN, dict(av, pool="mean"), a0, 93), ("tfngb", MM.TFN_GB, avg, a0g, 94)):
+        torch.manual_seed(seed)
+        m = cls(2, dict(v), dict(z))
+        for mod in m.modules():
+            if type(mod).__name__ == "NoiseLayer":
+                mod.std = 0.0
+        with torch.no_grad():
+            for k, p in m.named_parameters():
+                if p.dim() == 1 and (".norm" in k or "filter.2" in k or "connector.1" in k or "classifier.1" in k or "mlp.1" in k):
+                    (p.uniform_(0.5, 1.5) if k.endswith("weight") else p.normal_(0, 0.3))
+        sd0 = {k: t.detach().clone() for k, t in m.state_dict().items()}
+        m.train()
+        g = torch.Generator().manual_seed(seed + 100)
+        x_vis = torch.randn(4, 3, 5, 32, 32, generator=g)                 # (B, C, T, H, W), as the loaders deliver it
+        x_ts = torch.randn(4, 5, 6, generator=g)
+        outs = m(x_vis, x_ts)
+        outs = outs if isinstance(outs, tuple) else (outs,)
+        douts = [torch.randn(o.shape, generator=g) for o in outs]
+        sum((o * d).sum() for o, d in zip(outs, douts)).backward()
+        rec[tag + "/x_vis"] = x_vis.numpy(); rec[tag + "/x_ts"] = x_ts.numpy()
+        for i, (o, d) in enumerate(zip(outs, douts)):
+            rec["%s/out%d" % (tag, i)] = o.detach().numpy(); rec["%s/dout%d" % (tag, i)] = d.numpy()
+        for k, t in sd0.items():
+            rec[tag + "/sd/" + k] = t.numpy()
+        for k, p in m.named_parameters():
+            rec[tag + "/grad/" + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+        for k, t in m.state_dict().items():
+            if "running" in k:
+                rec[tag + "/after/" + k] = t.numpy()
+        print("multimodal", tag, [o.detach().numpy().ravel()[:2] for o in outs])
+    np.savez_compressed(os.path.join(HERE, "multimodal.npz"), **rec)
+
+
 if __name__ == "__main__":
     # Several seeds per configuration: LeakyReLU(0.01) makes the gradient discontinuous where a
     # pre-activation crosses zero, so two correct fp32 implementations can disagree by >1e-3 on a whole
@@ -482,3 +530,4 @@ if __name__ == "__main__":
     mlstm_fcn_fixture()
     transformer0d_fixture()
     vivit_fixture()
+    multimodal_fixture()

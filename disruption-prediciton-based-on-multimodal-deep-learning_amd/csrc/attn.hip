@@ -192,6 +192,284 @@ __global__ __launch_bounds__(256) void k_attn_bwd_kv(const float* __restrict__ q
 
 #undef ROW
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Matrix-core attention (exact fp32, v_mfma_f32_16x16x4_f32) for the unmasked, dropout-free case of ViViT's Attention
+// (ViViT.py:69-88; BASELINE cfg3: 84 sequences x 4 heads x 197 tokens x d_head 64).  S <= 256, d_head in {16, 32, 64}.
+// A wave owns 16 query (or key) rows; a workgroup (4 waves) 64.  Operand mapping as in conv_gemm.hip: lane (li = lane&15,
+// lg = lane>>4) supplies A[row li][k] and B[k][col li] with k = 4*lg + e for MFMA e of a group of 4 (a permutation of the K axis,
+// the same on both sides); the result tile holds D[row 4*lg + r][col li] in register r.
+//   scores (16 x S) = Qfrag . K^T : K rows staged 64 at a time in LDS (pitch 72: conflict-free ds_read_b128), all 16 x S
+//     scores live in <= 16 accumulator tiles per wave, so the softmax is done in registers (row = (lg, r): reduce over tiles and
+//     over the 16 lanes of the group);
+//   out (16 x dh) = P . V : P goes through a per-wave LDS buffer to turn the result layout into the A layout; V rows staged 64
+//     at a time (pitch 68: conflict-free ds_read_b32 for the four rows 4*lg + e).
+// Backward pass A has the same shape with (dO, V) in the first product and (dS, K) in the second; pass B (per 16 keys) reads
+// dS^T / P^T straight from global as A operands and stages Q / dO.
+#define AT_KP 72
+#define AT_VP 68
+#define AT_MAXT 16
+typedef const float* cfp;
+
+template <int DH, int P>
+__device__ __forceinline__ void at_stage(float* tile, cfp base, int width, int r0, int S, int B, int b, int bf) {
+  constexpr int CH = DH / 4;
+#pragma unroll
+  for (int k = 0; k < 64 * CH / 256; ++k) {
+    const int e = threadIdx.x + 256 * k, r = e / CH, c = e - r * CH, i = r0 + r;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < S) v = *(const float4*)(base + (bf ? (size_t)b * S + i : (size_t)i * B + b) * width + c * 4);
+    *(float4*)(tile + r * P + c * 4) = v;
+  }
+}
+// acc[t] (t < nt) = afrag (16 x DH) . rows^T for the rows of `base` (staged 64 at a time)
+template <int DH>
+__device__ __forceinline__ void at_scores(f32x4 (&acc)[AT_MAXT], const f32x4 (&a)[DH / 16], float* tile, cfp base, int width, int S,
+                                          int B, int b, int bf, int nt, int li, int lg) {
+#pragma unroll
+  for (int kt = 0; kt < AT_MAXT / 4; ++kt) {
+    if (kt * 4 < nt) {
+      __syncthreads();
+      at_stage<DH, AT_KP>(tile, base, width, kt * 64, S, B, b, bf);
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (kt * 4 + j < nt) {
+#pragma unroll
+          for (int s = 0; s < DH / 16; ++s) {
+            const f32x4 bv = *(const f32x4*)(tile + (16 * j + li) * AT_KP + (s * 4 + lg) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[kt * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][e], bv[e], acc[kt * 4 + j], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+}
+// o (16 x DH) = Pw (16 x nt*16, per-wave LDS buffer, pitch pp) . rows of `base` (staged 64 at a time)
+template <int DH>
+__device__ __forceinline__ void at_apply(f32x4 (&o)[DH / 16], const float* pw, int pp, float* tile, cfp base, int width, int S, int B,
+                                         int b, int bf, int nt, int li, int lg) {
+#pragma unroll
+  for (int jn = 0; jn < DH / 16; ++jn) o[jn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int kt = 0; kt * 4 < nt; ++kt) {
+    __syncthreads();
+    at_stage<DH, AT_VP>(tile, base, width, kt * 64, S, B, b, bf);
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (kt * 4 + ks < nt) {
+        const f32x4 av = *(const f32x4*)(pw + li * pp + kt * 64 + ks * 16 + lg * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float* row = tile + (ks * 16 + lg * 4 + e) * AT_VP + li;
+#pragma unroll
+          for (int jn = 0; jn < DH / 16; ++jn) o[jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], row[jn * 16], o[jn], 0, 0, 0);
+        }
+      }
+    }
+  }
+}
+__device__ __forceinline__ float at_group_max(float v) {
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float at_group_sum(float v) {
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void k_attn_mfma_fwd(cfp qkv, int S, int B, int D, int H, int bf, float scale, int pp,
+                                                      float* __restrict__ probs, float* __restrict__ out) {
+  extern __shared__ float sm[];
+  float* tile = sm;                                  // 64 x 72
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+  float* pw = sm + 64 * AT_KP + wave * 16 * pp;      // per-wave 16 x pp
+  const int bh = blockIdx.x, b = bh / H, h = bh - b * H, nt = (S + 15) >> 4;
+  const int q0 = blockIdx.y * 64 + wave * 16;
+  f32x4 a[DH / 16];
+  {
+    const int i = q0 + li;
+#pragma unroll
+    for (int s = 0; s < DH / 16; ++s) {
+      f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (i < S) v = *(const f32x4*)(qkv + (bf ? (size_t)b * S + i : (size_t)i * B + b) * 3 * D + h * DH + (s * 4 + lg) * 4);
+      a[s] = v * scale;
+    }
+  }
+  f32x4 acc[AT_MAXT];
+#pragma unroll
+  for (int t = 0; t < AT_MAXT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  at_scores<DH>(acc, a, tile, qkv + D + h * DH, 3 * D, S, B, b, bf, nt, li, lg);
+  // softmax over the key axis (columns 16 t + li), one row per (lg, r)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < AT_MAXT; ++t) if (t < nt && 16 * t + li < S) mx = fmaxf(mx, acc[t][r]);
+    mx = at_group_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < AT_MAXT; ++t) {
+      if (t < nt) { const float e = (16 * t + li < S) ? expf(acc[t][r] - mx) : 0.f; acc[t][r] = e; sum += e; }
+    }
+    const float inv = 1.f / at_group_sum(sum);
+    const int i = q0 + 4 * lg + r;
+#pragma unroll
+    for (int t = 0; t < AT_MAXT; ++t) {
+      if (t < nt) {
+        const float pv = acc[t][r] * inv;
+        pw[(4 * lg + r) * pp + 16 * t + li] = pv;
+        if (i < S && 16 * t + li < S) probs[((size_t)bh * S + i) * S + 16 * t + li] = pv;
+      }
+    }
+  }
+  f32x4 o[DH / 16];
+  at_apply<DH>(o, pw, pp, tile, qkv + 2 * D + h * DH, 3 * D, S, B, b, bf, nt, li, lg);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = q0 + 4 * lg + r;
+    if (i < S) {
+      float* dst = out + (bf ? (size_t)b * S + i : (size_t)i * B + b) * D + h * DH + li;
+#pragma unroll
+      for (int jn = 0; jn < DH / 16; ++jn) dst[jn * 16] = o[jn][r];
+    }
+  }
+}
+
+// pass A: dP = dO V^T; dS = P (dP - rowsum(dP P)) scale -> ds_out; dq = dS K
+template <int DH>
+__global__ __launch_bounds__(256) void k_attn_mfma_bwd_q(cfp qkv, cfp probs, cfp dout, int S, int B, int D, int H, int bf, float scale,
+                                                        int pp, float* __restrict__ ds_out, float* __restrict__ dqkv) {
+  extern __shared__ float sm[];
+  float* tile = sm;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+  float* pw = sm + 64 * AT_KP + wave * 16 * pp;
+  const int bh = blockIdx.x, b = bh / H, h = bh - b * H, nt = (S + 15) >> 4;
+  const int q0 = blockIdx.y * 64 + wave * 16;
+  f32x4 a[DH / 16];
+  {
+    const int i = q0 + li;
+#pragma unroll
+    for (int s = 0; s < DH / 16; ++s) {
+      f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (i < S) v = *(const f32x4*)(dout + (bf ? (size_t)b * S + i : (size_t)i * B + b) * D + h * DH + (s * 4 + lg) * 4);
+      a[s] = v;
+    }
+  }
+  f32x4 acc[AT_MAXT];
+#pragma unroll
+  for (int t = 0; t < AT_MAXT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  at_scores<DH>(acc, a, tile, qkv + 2 * D + h * DH, 3 * D, S, B, b, bf, nt, li, lg);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = q0 + 4 * lg + r;
+    float pr[AT_MAXT];
+    float dot = 0.f;
+#pragma unroll
+    for (int t = 0; t < AT_MAXT; ++t) {
+      pr[t] = 0.f;
+      if (t < nt) {
+        if (i < S && 16 * t + li < S) pr[t] = probs[((size_t)bh * S + i) * S + 16 * t + li];
+        dot = fmaf(acc[t][r], pr[t], dot);
+      }
+    }
+    dot = at_group_sum(dot);
+#pragma unroll
+    for (int t = 0; t < AT_MAXT; ++t) {
+      if (t < nt) {
+        const float dsv = pr[t] * (acc[t][r] - dot) * scale;
+        pw[(4 * lg + r) * pp + 16 * t + li] = dsv;
+        if (i < S && 16 * t + li < S) ds_out[((size_t)bh * S + i) * S + 16 * t + li] = dsv;
+      }
+    }
+  }
+  f32x4 o[DH / 16];
+  at_apply<DH>(o, pw, pp, tile, qkv + D + h * DH, 3 * D, S, B, b, bf, nt, li, lg);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = q0 + 4 * lg + r;
+    if (i < S) {
+      float* dst = dqkv + (bf ? (size_t)b * S + i : (size_t)i * B + b) * 3 * D + h * DH + li;
+#pragma unroll
+      for (int jn = 0; jn < DH / 16; ++jn) dst[jn * 16] = o[jn][r];
+    }
+  }
+}
+// pass B (per 16 keys j): dk[j] = sum_i dS[i][j] q[i];  dv[j] = sum_i P[i][j] dO[i]
+template <int DH>
+__global__ __launch_bounds__(256) void k_attn_mfma_bwd_kv(cfp qkv, cfp probs, cfp dout, cfp ds, int S, int B, int D, int H, int bf,
+                                                         float* __restrict__ dqkv) {
+  extern __shared__ float sm[];
+  float* tq = sm;                      // 64 x 68
+  float* td = sm + 64 * AT_VP;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+  const int bh = blockIdx.x, b = bh / H, h = bh - b * H, nt = (S + 15) >> 4;
+  const int j0 = blockIdx.y * 64 + wave * 16, j = j0 + li;
+  f32x4 dk[DH / 16], dv[DH / 16];
+#pragma unroll
+  for (int jn = 0; jn < DH / 16; ++jn) { dk[jn] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[jn] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  const float* dsb = ds + (size_t)bh * S * S;
+  const float* pb = probs + (size_t)bh * S * S;
+  for (int it = 0; it * 4 < nt; ++it) {
+    __syncthreads();
+    at_stage<DH, AT_VP>(tq, qkv + h * DH, 3 * D, it * 64, S, B, b, bf);
+    at_stage<DH, AT_VP>(td, dout + h * DH, D, it * 64, S, B, b, bf);
+    __syncthreads();
+#pragma unroll
+    for (int is = 0; is < 4; ++is) {
+      if (it * 4 + is < nt) {
+        float ads[4], ap[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = it * 64 + is * 16 + lg * 4 + e;
+          const bool ok = i < S && j < S;
+          ads[e] = ok ? dsb[(size_t)i * S + j] : 0.f;
+          ap[e] = ok ? pb[(size_t)i * S + j] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float* rq = tq + (is * 16 + lg * 4 + e) * AT_VP + li;
+          const float* rd = td + (is * 16 + lg * 4 + e) * AT_VP + li;
+#pragma unroll
+          for (int jn = 0; jn < DH / 16; ++jn) {
+            dk[jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(ads[e], rq[jn * 16], dk[jn], 0, 0, 0);
+            dv[jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[e], rd[jn * 16], dv[jn], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int jj = j0 + 4 * lg + r;
+    if (jj < S) {
+      float* dst = dqkv + (bf ? (size_t)b * S + jj : (size_t)jj * B + b) * 3 * D + h * DH + li;
+#pragma unroll
+      for (int jn = 0; jn < DH / 16; ++jn) { dst[D + jn * 16] = dk[jn][r]; dst[2 * D + jn * 16] = dv[jn][r]; }
+    }
+  }
+}
+static bool attn_use_mfma(const float* mask, const float* drop, int S, int D, int H) {
+  static const bool off = [] { const char* e = getenv("MD_ATTN_SCALAR"); return e && atoi(e) != 0; }();
+  const int dh = D / H;
+  return !off && !mask && !drop && S <= 16 * AT_MAXT && (dh == 16 || dh == 32 || dh == 64) && D % 4 == 0;
+}
+static bool attn_mfma_prepare() {        // raise the dynamic LDS limit of the attention kernels once
+  static const bool ok = [] {
+    bool good = true;
+    auto set = [&](const void* f) { good = good && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; };
+    set((const void*)k_attn_mfma_fwd<16>); set((const void*)k_attn_mfma_fwd<32>); set((const void*)k_attn_mfma_fwd<64>);
+    set((const void*)k_attn_mfma_bwd_q<16>); set((const void*)k_attn_mfma_bwd_q<32>); set((const void*)k_attn_mfma_bwd_q<64>);
+    return good;
+  }();
+  return ok;
+}
+static int attn_pp(int S) { return ((S + 15) & ~15) + 8; }       // pitch of the per-wave P buffer: = 8 (mod 16) floats
+static size_t attn_mfma_lds(int S) { return (size_t)(64 * AT_KP + 4 * 16 * attn_pp(S)) * 4; }
+
 // GELU.  kind 0: exact, 0.5 x (1 + erf(x / sqrt 2)) (nn.GELU, transformer.py:85); kind 1: the reference's own tanh form
 // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) (transformer.py:36-38).  bwd: dx = dy * gelu'(x).
 __global__ __launch_bounds__(256) void k_gelu(const float* __restrict__ x, const float* __restrict__ dy, int kind, int64_t n,
@@ -307,6 +585,21 @@ extern "C" int md_attention_fwd(const float* qkv, const float* mask, const float
                                 int32_t batch_first, float* probs, float* out, void* stream) {
   if (!qkv || !probs || !out) return MD_ERR_NULL;
   if (S <= 0 || B <= 0 || D <= 0 || H <= 0 || D % H) return MD_ERR_BAD_SHAPE;
+  if (attn_use_mfma(mask, drop, S, D, H)) {
+    if (!attn_mfma_prepare()) return MD_ERR_LAUNCH;
+    const dim3 grid(B * H, md_cdiv(S, 64));
+    const size_t l = attn_mfma_lds(S);
+    const float sc = 1.f / sqrtf((float)(D / H));
+    const int bf = batch_first ? 1 : 0, pp = attn_pp(S);
+    hipStream_t st = (hipStream_t)stream;
+    switch (D / H) {
+      case 16: MD_KLAUNCH(k_attn_mfma_fwd<16>, grid, dim3(256), l, st, qkv, S, B, D, H, bf, sc, pp, probs, out); break;
+      case 32: MD_KLAUNCH(k_attn_mfma_fwd<32>, grid, dim3(256), l, st, qkv, S, B, D, H, bf, sc, pp, probs, out); break;
+      default: MD_KLAUNCH(k_attn_mfma_fwd<64>, grid, dim3(256), l, st, qkv, S, B, D, H, bf, sc, pp, probs, out); break;
+    }
+    MD_CHECK_LAUNCH();
+    return MD_OK;
+  }
   const size_t lds = (size_t)ATT_RB * S * 4;
   if (lds > 60000) return MD_ERR_UNSUPPORTED;
   MD_KLAUNCH(k_attn_fwd, dim3(B * H, md_cdiv(S, ATT_RB)), dim3(256), lds, (hipStream_t)stream, qkv, mask, drop, S, B, D, H,
@@ -318,11 +611,31 @@ extern "C" int md_attention_bwd(const float* qkv, const float* probs, const floa
                                 int32_t D, int32_t H, int32_t batch_first, float* dqkv, float* ds_scratch, void* stream) {
   if (!qkv || !probs || !dout || !dqkv || !ds_scratch) return MD_ERR_NULL;
   if (S <= 0 || B <= 0 || D <= 0 || H <= 0 || D % H) return MD_ERR_BAD_SHAPE;
-  const size_t lds = (size_t)ATT_RB * S * 4;
-  if (lds > 60000) return MD_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   const float scale = 1.f / sqrtf((float)(D / H));
   const int bf = batch_first ? 1 : 0;
+  if (attn_use_mfma(nullptr, drop, S, D, H)) {
+    if (!attn_mfma_prepare()) return MD_ERR_LAUNCH;
+    const dim3 grid(B * H, md_cdiv(S, 64));
+    const size_t la = attn_mfma_lds(S), lb = (size_t)2 * 64 * AT_VP * 4;
+    const int pp = attn_pp(S);
+    const float* dsc = ds_scratch;
+    switch (D / H) {
+      case 16:
+        MD_KLAUNCH(k_attn_mfma_bwd_q<16>, grid, dim3(256), la, s, qkv, probs, dout, S, B, D, H, bf, scale, pp, ds_scratch, dqkv);
+        MD_KLAUNCH(k_attn_mfma_bwd_kv<16>, grid, dim3(256), lb, s, qkv, probs, dout, dsc, S, B, D, H, bf, dqkv); break;
+      case 32:
+        MD_KLAUNCH(k_attn_mfma_bwd_q<32>, grid, dim3(256), la, s, qkv, probs, dout, S, B, D, H, bf, scale, pp, ds_scratch, dqkv);
+        MD_KLAUNCH(k_attn_mfma_bwd_kv<32>, grid, dim3(256), lb, s, qkv, probs, dout, dsc, S, B, D, H, bf, dqkv); break;
+      default:
+        MD_KLAUNCH(k_attn_mfma_bwd_q<64>, grid, dim3(256), la, s, qkv, probs, dout, S, B, D, H, bf, scale, pp, ds_scratch, dqkv);
+        MD_KLAUNCH(k_attn_mfma_bwd_kv<64>, grid, dim3(256), lb, s, qkv, probs, dout, dsc, S, B, D, H, bf, dqkv); break;
+    }
+    MD_CHECK_LAUNCH();
+    return MD_OK;
+  }
+  const size_t lds = (size_t)ATT_RB * S * 4;
+  if (lds > 60000) return MD_ERR_UNSUPPORTED;
   MD_KLAUNCH(k_attn_bwd_q, dim3(B * H, md_cdiv(S, ATT_RB)), dim3(256), lds, s, qkv, probs, drop, dout, S, B, D, H, bf, scale, ds_scratch, dqkv);
   MD_CHECK_LAUNCH();
   MD_KLAUNCH(k_attn_bwd_kv, dim3(B * H, md_cdiv(S, ATT_RB)), dim3(256), 0, s, qkv, probs, drop, dout, (const float*)ds_scratch, S, B, D, H, bf, dqkv);

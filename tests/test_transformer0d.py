@@ -78,16 +78,20 @@ def test_native_module_matches_reference_fixture(golden_dir, exact):
 def test_attention_layernorm_gelu_ops_match_torch():
     torch.manual_seed(5)
     for S, B, D, H, masked in ((21, 3, 32, 4, True), (197, 2, 48, 3, False)):     # the 0D encoder's sequence; ViViT's 196+1 tokens
-        _check_attention(S, B, D, H, masked)
+        _check_attention(S, B, D, H, masked, True, False)
+    # no mask, no dropout: the matrix-core kernels (d_head 16 / 32 / 64; ragged last tiles; both layouts)
+    for S, B, D, H, bf in ((197, 2, 48, 3, True), (197, 3, 128, 2, True), (50, 3, 64, 2, False), (256, 1, 32, 1, True), (22, 4, 256, 4, True),
+                           (16, 2, 16, 1, False)):
+        _check_attention(S, B, D, H, False, False, bf)
     _check_ln_gelu()
 
 
-def _check_attention(S, B, D, H, masked):
+def _check_attention(S, B, D, H, masked, use_drop, batch_first):
     from src.models._unit import AttentionFunction
     dh = D // H
     qkv = torch.randn(S, B, 3 * D)
     mask = torch.triu(torch.full((S, S), float("-inf")), diagonal=1) if masked else torch.zeros(S, S)
-    drop = (torch.rand(B * H, S, S) > 0.2).float() / 0.8
+    drop = (torch.rand(B * H, S, S) > 0.2).float() / 0.8 if use_drop else torch.ones(B * H, S, S)
     qr = qkv.clone().requires_grad_(True)
     q, k, v = qr.chunk(3, dim=2)
     hd = lambda t: t.reshape(S, B * H, dh).transpose(0, 1)
@@ -95,14 +99,16 @@ def _check_attention(S, B, D, H, masked):
     ref = (p @ hd(v)).transpose(0, 1).reshape(S, B, D)
     dout = torch.randn(S, B, D)
     ref.backward(dout)
-    qg = qkv.cuda().requires_grad_(True)
-    out = AttentionFunction.apply(qg, mask.cuda(), H, drop.cuda())
-    out.backward(dout.cuda())
-    assert float((out.detach().cpu() - ref.detach()).abs().max()) < 2e-6
-    assert float((qg.grad.cpu() - qr.grad).abs().max()) < 2e-5
-    if not masked:
-        qg2 = qkv.cuda().requires_grad_(True)
-        out2 = AttentionFunction.apply(qg2, None, H, drop.cuda()); out2.backward(dout.cuda())
+    lay = (lambda t: t.transpose(0, 1).contiguous()) if batch_first else (lambda t: t)
+    qg = lay(qkv).cuda().requires_grad_(True)
+    out = AttentionFunction.apply(qg, mask.cuda() if masked else None, H, drop.cuda() if use_drop else None, batch_first)
+    out.backward(lay(dout).cuda())
+    tag = (S, B, D, H, masked, use_drop, batch_first)
+    assert float((out.detach().cpu() - lay(ref.detach())).abs().max()) < 3e-6, tag
+    assert float((qg.grad.cpu() - lay(qr.grad)).abs().max()) < 3e-5, tag
+    if not masked and use_drop:
+        qg2 = lay(qkv).cuda().requires_grad_(True)
+        out2 = AttentionFunction.apply(qg2, torch.zeros(S, S).cuda(), H, drop.cuda(), batch_first); out2.backward(lay(dout).cuda())
         assert torch.equal(out2, out) and torch.equal(qg2.grad, qg.grad)
 
 

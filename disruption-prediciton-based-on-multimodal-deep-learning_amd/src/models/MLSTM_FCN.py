@@ -136,7 +136,9 @@ class MLSTM_FCN(nn.Module):
         return linear(torch.cat([x_rnn, x_fcn], dim=1), self.converter)
 
     def forward(self, x: torch.Tensor):
-        f = self._features(x)
+        return self._head(self._features(x))
+
+    def _head(self, f: torch.Tensor):
         lin0, bn, act, lin1 = self.classifier[0], self.classifier[1], self.classifier[2], self.classifier[3]
         slope = float(act.negative_slope)
         out = HeadFunction.apply(f, lin0.weight, lin0.bias, bn.weight, bn.bias, lin1.weight, lin1.bias, bn.running_mean,

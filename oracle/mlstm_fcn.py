@@ -8,7 +8,7 @@ from .cnnlstm import _lstm_dir
 
 
 def mlstm_fcn_forward(x, sd, kernel_size: int, stride: int, lstm_n_layers: int, bidirectional: bool, alpha: float,
-                      training: bool = True):
+                      training: bool = True, return_latent: bool = False):
     # RNN branch (:54-68)
     out = x.permute(1, 0, 2)
     for layer in range(lstm_n_layers):
@@ -32,6 +32,10 @@ def mlstm_fcn_forward(x, sd, kernel_size: int, stride: int, lstm_n_layers: int, 
         y = y * g[:, :, None]
     x_fcn = y.mean(dim=2)
     f = F.linear(torch.cat([x_rnn, x_fcn], dim=1), sd["converter.weight"], sd["converter.bias"])              # :137-138
+    return f if return_latent else mlstm_fcn_head(f, sd, alpha, training)
+
+
+def mlstm_fcn_head(f, sd, alpha: float, training: bool = True):
     h = F.linear(f, sd["classifier.0.weight"], sd["classifier.0.bias"])
     h = F.leaky_relu(F.batch_norm(h, sd["classifier.1.running_mean"], sd["classifier.1.running_var"], sd["classifier.1.weight"],
                                   sd["classifier.1.bias"], training, 0.1, 1e-5), alpha)

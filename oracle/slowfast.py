@@ -25,7 +25,8 @@ def _layer(x, sd, p, nblocks, stride, head_conv, training):
     return x
 
 
-def slowfast_forward(x, sd, layers, alpha: int = 4, tau_fast: int = 1, alpha_elu: float = 1.0, training: bool = True):
+def slowfast_forward(x, sd, layers, alpha: int = 4, tau_fast: int = 1, alpha_elu: float = 1.0, training: bool = True,
+                     return_latent: bool = False):
     xs, xf = x[:, :, ::tau_fast * alpha], x[:, :, ::tau_fast]                                                 # slowfast.py:120-128
     pf, ps = "encoder.fastnet.", "encoder.slownet."
     lat = []
@@ -43,6 +44,12 @@ def slowfast_forward(x, sd, layers, alpha: int = 4, tau_fast: int = 1, alpha_elu
     s = _layer(torch.cat([s, lat[3]], 1), sd, ps + "layer4.", layers[3], 2, 3, training)
     s = F.adaptive_avg_pool3d(s, 1).view(-1, s.size(1))                                                       # :33-34
     feat = torch.cat([s, f], dim=1)                                                                           # :134
+    if return_latent:
+        return feat
+    return slowfast_head(feat, sd, alpha_elu, training)
+
+
+def slowfast_head(feat, sd, alpha_elu: float = 1.0, training: bool = True):
     c = "classifier.classifier."
     h = F.linear(feat, sd[c + "0.weight"], sd[c + "0.bias"])                                                  # :157
     h = F.elu(F.batch_norm(h, sd[c + "1.running_mean"], sd[c + "1.running_var"], sd[c + "1.weight"], sd[c + "1.bias"],

@@ -11,6 +11,16 @@ def _gelu_tanh(x):
     return 0.5 * x * (1 + torch.tanh(math.sqrt(2 / math.pi) * (x + 0.044715 * torch.pow(x, 3))))       # transformer.py:36-37
 
 
+def positional_table(max_len: int, d_model: int):
+    """PositionalEncoding.pe (transformer.py:10-28): (max_len, 1, d_model), sin on even and cos on odd features."""
+    pe = torch.zeros(max_len, d_model)
+    pos = torch.arange(0, max_len).float().unsqueeze(1)
+    div = (torch.arange(0, d_model, 2).float() * -(math.log(10000.0) / d_model)).exp()
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)[:, : d_model // 2]
+    return pe.unsqueeze(1)
+
+
 def transformer0d_forward(x, sd, n_layers: int, n_heads: int, kernel_size: int, training: bool = True, with_classifier: bool = True):
     e = "encoder."
     pad = (kernel_size - 1) // 2

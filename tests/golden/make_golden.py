@@ -507,6 +507,80 @@ def multimodal_fixture():
     np.savez_compressed(os.path.join(HERE, "multimodal.npz"), **rec)
 
 
+def fusion_derived_fixture():
+    """DERIVED fusion models for BASELINE configs 4 and 5: the reference's own R2Plus1DClassifier + Transformer, and
+    SlowFast + MLSTM_FCN, combined by the recipe of its MultiModalModel_GB (MultiModal.py:65-77,96-97,131-149: forward hooks on
+    the first Linear of each head capture the latents; connector Linear+ReLU; classifier Linear, LayerNorm, ReLU, Linear).
+    Weights from the NumPy recipe oracle.fusion.fusion_state (seed stored, not megabytes), tiny shapes, noise std / dropout 0.
+    Stored: inputs, the three logit sets, the blended loss (GradientBlending, :45-50) and sub-sampled gradients + norms."""
+    import torch.nn as nn
+    from src.models.slowfast import SlowFast
+    from src.models.transformer import Transformer
+    from src.models.MLSTM_FCN import MLSTM_FCN
+    from src.GradientBlending import GradientBlending
+    from oracle import fusion as ofu
+
+    class DerivedGB(nn.Module):
+        def __init__(self, vis, ts, vis_first_linear, ts_first_linear, dims):
+            super().__init__()
+            self.vis_model, self.ts_model = vis, ts
+            self.connector = nn.Sequential(nn.Linear(dims, dims // 2), nn.ReLU())
+            self.classifier = nn.Sequential(nn.Linear(dims // 2, dims // 2), nn.LayerNorm(dims // 2), nn.ReLU(), nn.Linear(dims // 2, 2))
+            self.lat = {}
+            vis_first_linear.register_forward_hook(lambda m, i, o: self.lat.__setitem__("vis", i))
+            ts_first_linear.register_forward_hook(lambda m, i, o: self.lat.__setitem__("ts", i))
+
+        def forward(self, x_vis, x_ts):
+            out_vis = self.vis_model(x_vis)
+            out_ts = self.ts_model(x_ts)
+            x = torch.cat([self.lat["vis"][0], self.lat["ts"][0]], axis=1)
+            return self.classifier(self.connector(x)), out_vis, out_ts
+
+    rec = {}
+    for tag, seed in (("cfg4", 101), ("cfg5", 111)):
+        torch.manual_seed(seed)
+        if tag == "cfg4":
+            vis = R2Plus1DClassifier(input_size=(3, 5, 24, 24), num_classes=2, layer_sizes=[1, 1, 1, 1], alpha=0.01)
+            ts = Transformer(n_features=6, kernel_size=3, feature_dims=16, max_len=5, n_layers=1, n_heads=2, dim_feedforward=24,
+                             dropout=0.0, cls_dims=12, n_classes=2)
+            m = DerivedGB(vis, ts, vis.linear[0], ts.classifier[0], 128 + 16)
+            x_vis = torch.randn(4, 3, 5, 24, 24, generator=torch.Generator().manual_seed(seed + 1))
+            x_ts = torch.randn(4, 5, 6, generator=torch.Generator().manual_seed(seed + 2))
+            loss_fn = FocalLoss(torch.tensor([1.0, 1.0]), 2.0)
+        else:
+            vis = SlowFast(input_shape=(3, 8, 32, 32), layers=[1, 1, 1, 1], alpha=4, tau_fast=1, num_classes=2, alpha_elu=1.0)
+            ts = MLSTM_FCN(n_features=6, fcn_dim=8, kernel_size=3, stride=1, seq_len=8, lstm_dim=8, lstm_n_layers=1,
+                           lstm_bidirectional=True, lstm_dropout=0.0, reduction=4, alpha=0.01, n_classes=2)
+            m = DerivedGB(vis, ts, vis.classifier.classifier[0], ts.classifier[0], vis.classifier.input_dim + ts.converter.out_features)
+            x_vis = torch.randn(4, 3, 8, 32, 32, generator=torch.Generator().manual_seed(seed + 1))
+            x_ts = torch.randn(4, 8, 6, generator=torch.Generator().manual_seed(seed + 2))
+            loss_fn = LDAMLoss([100, 2000], max_m=0.5, weight=torch.tensor([1.0, 1.0]), s=1.0)
+        for mod in m.modules():
+            if type(mod).__name__ == "NoiseLayer":
+                mod.std = 0.0
+        m.load_state_dict(ofu.fusion_state({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed), strict=False)
+        m.train()
+        y = torch.tensor([0, 1, 1, 0])
+        outs = m(x_vis, x_ts)
+        gb = GradientBlending(loss_fn, loss_fn, loss_fn, 0.1, 0.4, 0.5)
+        L = gb(outs[0], outs[1], outs[2], y)
+        L.backward()
+        rec.update({tag + "/seed": seed, tag + "/x_vis": x_vis.numpy(), tag + "/x_ts": x_ts.numpy(), tag + "/y": y.numpy(),
+                    tag + "/loss": L.detach().numpy()})
+        for i, o in enumerate(outs):
+            rec["%s/out%d" % (tag, i)] = o.detach().numpy()
+        for k, v in m.state_dict().items():
+            rec[tag + "/shape/" + k] = np.array(tuple(v.shape), dtype=np.int64)
+            if "running" in k:
+                rec[tag + "/after/" + k] = v.numpy()
+        for k, p in m.named_parameters():
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            rec[tag + "/gsub/" + k] = subsample(g)
+            rec[tag + "/gnorm/" + k] = np.float64(g.double().norm())
+        print("fusion_derived", tag, float(L), [o.detach().numpy().ravel()[:2] for o in outs])
+    np.savez_compressed(os.path.join(HERE, "fusion_derived.npz"), **rec)
+
+
 if __name__ == "__main__":
     # Several seeds per configuration: LeakyReLU(0.01) makes the gradient discontinuous where a
     # pre-activation crosses zero, so two correct fp32 implementations can disagree by >1e-3 on a whole
@@ -531,3 +605,4 @@ if __name__ == "__main__":
     transformer0d_fixture()
     vivit_fixture()
     multimodal_fixture()
+    fusion_derived_fixture()

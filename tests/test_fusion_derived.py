@@ -1,0 +1,134 @@
+"""BASELINE configs 4 and 5 as parity cases (SURVEY 8c "derived fusion oracles"): R2Plus1DClassifier + Transformer-0D with
+GradientBlending(Focal), and SlowFast + MLSTM_FCN with GradientBlending(LDAM) - the reference's MultiModalModel_GB recipe applied
+to encoder pairs it never wires itself.  The fixture is recorded from the reference's own model classes combined by forward
+hooks (tests/golden/make_golden.py::fusion_derived_fixture); weights come from the seeded NumPy recipe.
+CPU: the composed oracle restatement against the fixture (logits 5e-5 of their scale, blended loss 1e-5, running statistics).
+GPU: the native FusionGB: logits and loss within 1e-3, sub-sampled gradients / gradient norms within 3e-3 (analytically-zero
+gradients bounded), running statistics 1e-4."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fusion as ofu
+from oracle import losses as ol
+
+MLSTM = dict(kernel_size=3, stride=1, lstm_n_layers=1, bidirectional=True, alpha=0.01)
+
+
+def _load(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, "fusion_derived.npz"))
+    pre = tag + "/shape/"
+    shapes = {k[len(pre):]: tuple(int(v) for v in g[k]) for k in g.files if k.startswith(pre)}
+    return g, shapes
+
+
+def _oracle_outs(tag, g, sd):
+    xv, xt = torch.from_numpy(g[tag + "/x_vis"]), torch.from_numpy(g[tag + "/x_ts"])
+    if tag == "cfg4":
+        return ofu.r2p1d_transformer_forward(xv, xt, sd, [1, 1, 1, 1], 0.01, 1, 2, 3, True)
+    return ofu.slowfast_mlstm_forward(xv, xt, sd, [1, 1, 1, 1], 4, 1.0, MLSTM, True)
+
+
+def _oracle_loss(tag, outs, y):
+    w = torch.tensor([1.0, 1.0])
+    if tag == "cfg4":
+        f = lambda o: ol.focal_loss(o, y, w, 2.0)
+    else:
+        m = ol.ldam_margins([100, 2000], 0.5)
+        f = lambda o: ol.ldam_loss(o, y, m, w, 1.0)
+    return ol.gradient_blending(f(outs[0]), f(outs[1]), f(outs[2]), 0.1, 0.4, 0.5)
+
+
+@pytest.mark.parametrize("tag", ["cfg4", "cfg5"])
+def test_oracle_matches_derived_fixture(golden_dir, tag):
+    g, shapes = _load(golden_dir, tag)
+    sd = ofu.fusion_state(shapes, int(g[tag + "/seed"]))
+    if tag == "cfg4":                                   # the constant sinusoidal table (transformer.py:10-28)
+        from oracle.transformer0d import positional_table
+        sd["ts_model.encoder.pos_enc.pe"] = positional_table(*shapes["ts_model.encoder.pos_enc.pe"][::2])
+    outs = _oracle_outs(tag, g, sd)
+    for i, o in enumerate(outs):
+        r = torch.from_numpy(g["%s/out%d" % (tag, i)])
+        assert float((o - r).abs().max()) <= 5e-5 * max(1.0, float(r.abs().max())), i
+    L = _oracle_loss(tag, outs, torch.from_numpy(g[tag + "/y"]))
+    assert abs(float(L) - float(g[tag + "/loss"])) <= 1e-5 * max(1.0, abs(float(g[tag + "/loss"])))
+    for k in g.files:
+        if k.startswith(tag + "/after/"):
+            name = k[len(tag) + 7:]
+            assert float((sd[name] - torch.from_numpy(g[k])).abs().max()) <= 2e-6 * max(1.0, float(np.abs(g[k]).max())), name
+
+
+def _native(tag):
+    from src.models.fusion import FusionGB
+    from src.models.MLSTM_FCN import MLSTM_FCN
+    from src.models.R2Plus1D import R2Plus1DClassifier
+    from src.models.slowfast import SlowFast
+    from src.models.transformer import Transformer
+    if tag == "cfg4":
+        vis = R2Plus1DClassifier(input_size=(3, 5, 24, 24), num_classes=2, layer_sizes=[1, 1, 1, 1], alpha=0.01)
+        ts = Transformer(n_features=6, kernel_size=3, feature_dims=16, max_len=5, n_layers=1, n_heads=2, dim_feedforward=24, dropout=0.0,
+                         cls_dims=12, n_classes=2)
+    else:
+        vis = SlowFast(input_shape=(3, 8, 32, 32), layers=[1, 1, 1, 1], alpha=4, tau_fast=1, num_classes=2, alpha_elu=1.0)
+        ts = MLSTM_FCN(n_features=6, fcn_dim=8, kernel_size=3, stride=1, seq_len=8, lstm_dim=8, lstm_n_layers=1, lstm_bidirectional=True,
+                       lstm_dropout=0.0, reduction=4, alpha=0.01, n_classes=2)
+    return FusionGB(2, vis, ts)
+
+
+@pytest.mark.parametrize("tag", ["cfg4", "cfg5"])
+def test_native_model_has_the_derived_state_dict(golden_dir, tag):
+    g, shapes = _load(golden_dir, tag)
+    mine = _native(tag).state_dict()
+    assert set(mine) == set(shapes)
+    for k, shp in shapes.items():
+        assert tuple(mine[k].shape) == shp, k
+
+
+def _sub(t, n=48):
+    f = t.detach().reshape(-1)
+    return f[::max(1, f.numel() // n)][:n]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["cfg4", "cfg5"])
+def test_native_fusion_matches_derived_fixture(golden_dir, tag):
+    from src.GradientBlending import GradientBlending
+    from src.loss import FocalLoss, LDAMLoss
+    g, shapes = _load(golden_dir, tag)
+    m = _native(tag)
+    missing = m.load_state_dict(ofu.fusion_state(shapes, int(g[tag + "/seed"])), strict=False)
+    assert all(k.endswith("pos_enc.pe") for k in missing.missing_keys) and not missing.unexpected_keys
+    for mod in m.modules():
+        if type(mod).__name__ == "NoiseLayer":
+            mod.std = 0.0
+    m.cuda().train()
+    w = torch.tensor([1.0, 1.0]).cuda()
+    loss_fn = FocalLoss(w, 2.0) if tag == "cfg4" else LDAMLoss([100, 2000], max_m=0.5, weight=w, s=1.0)
+    gb = GradientBlending(loss_fn, loss_fn, loss_fn, 0.1, 0.4, 0.5)
+    outs = m(torch.from_numpy(g[tag + "/x_vis"]).cuda(), torch.from_numpy(g[tag + "/x_ts"]).cuda())
+    L = gb(outs[0], outs[1], outs[2], torch.from_numpy(g[tag + "/y"]).cuda())
+    L.backward()
+    torch.cuda.synchronize()
+    for i, o in enumerate(outs):
+        r = torch.from_numpy(g["%s/out%d" % (tag, i)])
+        assert float((o.detach().cpu() - r).abs().max()) <= 1e-3 * max(1.0, float(r.abs().max())), i
+    assert abs(float(L) - float(g[tag + "/loss"])) <= 1e-3 * max(1.0, abs(float(g[tag + "/loss"])))
+    gmax = max(float(g[k]) for k in g.files if k.startswith(tag + "/gnorm/"))
+    for k, p in m.named_parameters():
+        rn = float(g["%s/gnorm/%s" % (tag, k)])
+        got = p.grad.cpu() if p.grad is not None else torch.zeros(p.shape)
+        if rn < 1e-5 * gmax:                              # analytically zero (bias in front of a training-mode BatchNorm, ...)
+            assert float(got.double().norm()) < 1e-3 * gmax, k
+            continue
+        assert abs(float(got.double().norm()) - rn) <= 3e-3 * rn, (k, float(got.double().norm()), rn)
+        rs = torch.from_numpy(g["%s/gsub/%s" % (tag, k)])
+        assert float((_sub(got) - rs).abs().max()) <= 3e-3 * max(float(rs.abs().max()), rn / max(1.0, got.numel() ** 0.5)), k
+    after = m.state_dict()
+    for k in g.files:
+        if k.startswith(tag + "/after/"):
+            name = k[len(tag) + 7:]
+            assert float((after[name].cpu() - torch.from_numpy(g[k])).abs().max()) <= 1e-4 * max(1.0, float(np.abs(g[k]).max())), name
+    m.update_use_stream("multi")
+    assert tuple(m(torch.from_numpy(g[tag + "/x_vis"]).cuda(), torch.from_numpy(g[tag + "/x_ts"]).cuda()).shape) == (4, 2)

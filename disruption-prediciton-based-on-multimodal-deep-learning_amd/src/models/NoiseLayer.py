@@ -35,5 +35,26 @@ class NoiseLayer(nn.Module):
         if not self.training:
             return x
         ops.require_cuda(x)
-        noise = torch.randn(x.size()).to(x.device)              # CPU generator, as the reference
-        return _AddNoise.apply(ops.f32(x), noise, self.mean, self.std)
+        return _AddNoise.apply(ops.f32(x), self._draw(x), self.mean, self.std)
+
+    def __getstate__(self):                                      # the staging ring (pinned memory, events) is per process
+        return {k: v for k, v in self.__dict__.items() if k != "_ring"}
+
+    def __deepcopy__(self, memo):
+        return NoiseLayer(self.mean, self.std).train(self.training)
+
+    def _draw(self, x):
+        """torch.randn(x.size()) from the CPU default generator, as the reference, drawn into a pinned staging buffer (ring of 4,
+        one event each) and uploaded without blocking the host: the reference's pageable `.to(device)` waits for everything
+        queued on the stream before it."""
+        ring = self.__dict__.setdefault("_ring", {"i": 0, "slots": [None] * 4})
+        i = ring["i"] = (ring["i"] + 1) % 4
+        slot = ring["slots"][i]
+        if slot is None or slot[0].shape != x.shape:
+            slot = ring["slots"][i] = (torch.empty(x.shape, dtype=torch.float32).pin_memory(), torch.cuda.Event())
+        else:
+            slot[1].synchronize()                                # the upload that last used this buffer has finished
+        torch.randn(x.size(), out=slot[0])
+        noise = slot[0].to(x.device, non_blocking=True)
+        slot[1].record(torch.cuda.current_stream(x.device))
+        return noise

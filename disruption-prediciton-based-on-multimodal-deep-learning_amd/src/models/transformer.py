@@ -106,7 +106,10 @@ class TransformerEncoder(nn.Module):
     def forward(self, x: torch.Tensor):
         x = self.noise(x)
         x = self._filter(x.permute(0, 2, 1)).permute(2, 0, 1).contiguous()          # (T, B, D)
-        self.src_mask = self._generate_square_subsequent_mask(len(x), x.device)
+        # the reference rebuilds the (constant) causal mask on the CPU and uploads it every forward (:98-99), which puts a
+        # synchronous host-to-device copy into every step; it is built once per (length, device) here
+        if self.src_mask is None or self.src_mask.shape[0] != len(x) or self.src_mask.device != x.device:
+            self.src_mask = self._generate_square_subsequent_mask(len(x), x.device)
         x = self.pos_enc(x)
         for layer in self.transformer_encoder.layers:
             x = self._layer(x, layer, self.src_mask)

@@ -132,3 +132,41 @@ def test_native_fusion_matches_derived_fixture(golden_dir, tag):
             assert float((after[name].cpu() - torch.from_numpy(g[k])).abs().max()) <= 1e-4 * max(1.0, float(np.abs(g[k]).max())), name
     m.update_use_stream("multi")
     assert tuple(m(torch.from_numpy(g[tag + "/x_vis"]).cuda(), torch.from_numpy(g[tag + "/x_ts"]).cuda()).shape) == (4, 2)
+
+
+@pytest.mark.gpu
+def test_train_per_epoch_drives_the_fused_model():
+    """The reference's test strategy for its models (test/test_model.py: parameters must change, loss finite) on the cfg4 pair
+    through the mirrored train_per_epoch in 'multi-GB' mode with the fused clip + AdamW step."""
+    from torch.utils.data import DataLoader, Dataset
+    from src.GradientBlending import GradientBlending
+    from src.loss import FocalLoss
+    from src.optim import ClipAdamW
+    from src.train import train_per_epoch, valid_per_epoch
+
+    class Pairs(Dataset):
+        def __init__(self):
+            g = torch.Generator().manual_seed(5)
+            self.v = torch.randn(8, 3, 5, 24, 24, generator=g); self.t = torch.randn(8, 5, 6, generator=g)
+            self.y = torch.tensor([0, 1, 0, 1, 1, 0, 0, 1])
+
+        def __len__(self):
+            return 8
+
+        def __getitem__(self, i):
+            return {"video": self.v[i], "0D": self.t[i]}, self.y[i]
+
+    torch.manual_seed(6)
+    m = _native("cfg4").cuda()
+    before = {k: v.detach().clone() for k, v in m.named_parameters()}
+    w = torch.tensor([1.0, 1.0]).cuda()
+    gb = GradientBlending(FocalLoss(w, 2.0), FocalLoss(w, 2.0), FocalLoss(w, 2.0), 0.1, 0.4, 0.5)
+    opt = ClipAdamW(m.parameters(), lr=1e-3, max_norm=1.0)
+    loader = DataLoader(Pairs(), batch_size=4, shuffle=False)
+    for _ in range(2):
+        loss, acc, f1 = train_per_epoch(loader, m, opt, None, gb, "cuda:0", 1.0, "multi-GB")
+    assert np.isfinite(loss) and 0.0 <= acc <= 1.0
+    changed = [k for k, v in m.named_parameters() if not torch.equal(v.detach(), before[k])]
+    assert len(changed) > 0.9 * len(before)
+    vloss, vacc, vf1 = valid_per_epoch(loader, m, opt, gb, "cuda:0", "multi-GB")
+    assert np.isfinite(vloss)

@@ -1,0 +1,50 @@
+"""BASELINE config 4 on one GPU: R2Plus1D [1,2,2,1] (B=8, 3x21x128x128) + Transformer-0D (18 features, d 128, 4 layers, 8 heads,
+FF 1024, dropout 0.1) fused by the MultiModalModel_GB recipe (src/models/fusion.py), GradientBlending(0.1/0.4/0.5) over FocalLoss,
+ClipAdamW step.  One full training step timed after warm-up; the multi-GPU form is this step under src.distributed.
+python tools/cfg4_smoke.py [steps]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'disruption-prediciton-based-on-multimodal-deep-learning_amd'))
+import torch
+from src.GradientBlending import GradientBlending
+from src.loss import FocalLoss
+from src.models.fusion import FusionGB
+from src.models.R2Plus1D import R2Plus1DClassifier
+from src.models.transformer import Transformer
+from src.optim import ClipAdamW
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+torch.manual_seed(0)
+vis = R2Plus1DClassifier(input_size=(3, 21, 128, 128), num_classes=2, layer_sizes=[1, 2, 2, 1], alpha=0.01)
+ts = Transformer(n_features=18, kernel_size=5, feature_dims=128, max_len=21, n_layers=4, n_heads=8, dim_feedforward=1024, dropout=0.1,
+                 cls_dims=64, n_classes=2)
+m = FusionGB(2, vis, ts).cuda().train()
+w = torch.tensor([1.0, 1.0], device="cuda")
+gb = GradientBlending(FocalLoss(w, 2.0), FocalLoss(w, 2.0), FocalLoss(w, 2.0), 0.1, 0.4, 0.5)
+opt = ClipAdamW(m.parameters(), lr=2e-4, max_norm=1.0)
+xv = torch.randn(8, 3, 21, 128, 128, device="cuda"); xt = torch.randn(8, 21, 18, device="cuda")
+y = torch.tensor([0, 1, 0, 0, 1, 0, 0, 0], device="cuda")
+
+
+def step():
+    opt.zero_grad(set_to_none=True)
+    o = m(xv, xt)
+    loss = gb(o[0], o[1], o[2], y)
+    loss.backward()
+    opt.step()
+    return loss
+
+
+for _ in range(3):
+    step()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(steps):
+    loss = step()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+print(f"cfg4 fused R2Plus1D+Transformer GB step, B=8: {dt * 1e3:.2f} ms/step  ({8 / dt:.1f} clips/s)  loss {float(loss.detach()):.4f}")
+if os.environ.get("CFG4_PROFILE"):
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+        step(); torch.cuda.synchronize()
+    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=14, max_name_column_width=50))
+    print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=14, max_name_column_width=50))

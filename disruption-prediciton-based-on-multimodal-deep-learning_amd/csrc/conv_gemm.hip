@@ -461,7 +461,11 @@ extern "C" int32_t md_conv_fwd_stat_blocks(const MdConvDesc* d) {
 static int launch_gemm(const Geom& g, const float* src, const float* ps, const float* psh, float slope,
                        const float* wp, float* dst, float* stat, int accumulate, hipStream_t s) {
   if (ps != nullptr && g.Cpi > MAXC_PROLOGUE) return MD_ERR_UNSUPPORTED;
-  const int npb = pick_n_per_blk(g.N16);
+  int npb = pick_n_per_blk(g.N16);
+  // 128-row tiles alone may not fill the chip (a Linear over 16 548 tokens is 130 of them): split the destination channels
+  // further until there are about two workgroups per CU (the source tile is then read once per split; measured: ViViT cfg3 step 6.27 -> 5.91 ms)
+  static const int fill = getenv("MD_GEMM_FILL") ? atoi(getenv("MD_GEMM_FILL")) : 512;
+  while (md_cdiv(g.M, BM) * md_cdiv(g.N16, npb) < fill && npb > 32) npb = md_round_up(npb / 2, 16);
   dim3 grid(md_cdiv(g.M, BM), md_cdiv(g.N16, npb));
   static bool attr_set = false;
   const size_t lds = conv_gemm_lds_bytes();

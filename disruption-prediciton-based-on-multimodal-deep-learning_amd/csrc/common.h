@@ -56,6 +56,8 @@ __device__ __forceinline__ float md_dleaky(float pre, float slope) { return pre 
 
 // ---- unit-stride patch kernel (conv_patch.hip); used by the dispatchers in conv_gemm.hip
 struct PGeom;
+int linear_split_launch(int f16, const float* A, int M, int K, const float* W, int Kp, int N16, float* C, int ldc, int accumulate,
+                        hipStream_t s);   // MD_ERR_UNSUPPORTED when the caller should use k_conv_gemm
 struct PatchPlan;   // cached PGeom + LDS size for one (descriptor, direction)
 const PatchPlan* patch_lookup(const MdConvDesc* d, int dgrad);     // nullptr when the geometry does not qualify
 size_t patch_wpack_floats(const PatchPlan* p);

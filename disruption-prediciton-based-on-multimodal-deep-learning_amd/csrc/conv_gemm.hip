@@ -458,6 +458,10 @@ extern "C" int32_t md_conv_fwd_stat_blocks(const MdConvDesc* d) {
   return md_cdiv(d->N * d->To * d->Ho * d->Wo, BM);
 }
 
+static bool is_pure_gemm(const MdConvDesc* d) {       // a Linear over rows: 1x1x1, unit stride, no padding
+  return d->kt == 1 && d->kh == 1 && d->kw == 1 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 && d->ph == 0 && d->pw == 0;
+}
+
 static int launch_gemm(const Geom& g, const float* src, const float* ps, const float* psh, float slope,
                        const float* wp, float* dst, float* stat, int accumulate, hipStream_t s) {
   if (ps != nullptr && g.Cpi > MAXC_PROLOGUE) return MD_ERR_UNSUPPORTED;
@@ -486,6 +490,9 @@ extern "C" int md_conv_fwd(const MdConvDesc* d, const MdActView* x, const float*
   if (const PatchPlan* pp = patch_lookup(d, 0))
     return patch_launch(pp, x->data, x->scale, x->shift, x->slope, wpack_fwd, y_raw, stat_partial, 0, (hipStream_t)stream);
   Geom g = geom_fwd(d);
+  if (is_pure_gemm(d) && !x->scale && !stat_partial &&
+      linear_split_launch(1, x->data, g.M, g.Kc * 4, wpack_fwd, g.Kp, g.N16, y_raw, g.Cpo, 0, (hipStream_t)stream) == MD_OK)
+    return MD_OK;
   return launch_gemm(g, x->data, x->scale, x->shift, x->slope, wpack_fwd, y_raw, stat_partial, 0, (hipStream_t)stream);
 }
 
@@ -497,6 +504,9 @@ extern "C" int md_conv_dgrad(const MdConvDesc* d, const float* dy_raw, const flo
   if (const PatchPlan* pp = patch_lookup(d, 1))
     return patch_launch(pp, dy_raw, nullptr, nullptr, 1.f, wpack_dgrad, dx, nullptr, accumulate, (hipStream_t)stream);
   Geom g = geom_dgrad(d);
+  if (is_pure_gemm(d) &&
+      linear_split_launch(0, dy_raw, g.M, g.Kc * 4, wpack_dgrad, g.Kp, g.N16, dx, g.Cpo, accumulate, (hipStream_t)stream) == MD_OK)
+    return MD_OK;
   return launch_gemm(g, dy_raw, nullptr, nullptr, 1.f, wpack_dgrad, dx, nullptr, accumulate, (hipStream_t)stream);
 }
 

@@ -1549,3 +1549,117 @@ int wgrad_patch_launch(const WgradPlan* p, const MdConvDesc* d, const float* src
   MD_CHECK_LAUNCH();
   return MD_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------------------------------
+// K-streaming split-precision GEMM for the Linears whose source width exceeds the patch kernels' LDS budget (more than 320
+// channels: ViViT's patch embedding 768 -> 128 and FeedForward 1024 -> 128, the data gradients of qkv / FF1, the 0D Transformer's
+// FF): C[M][ldc] (+)= A[M][K] . W[N16][Kp]^T with A, W, C in fp32 and every product as three fp16 (forward) or bf16 (data
+// gradient) MFMAs, exactly as in k_conv_patch.  128 rows x npb (32 / 64 / 128) columns per workgroup, 32 k per stage; wave w owns
+// rows 32 w .. 32 w + 31 and all columns.  Both operands are split into hi / lo halves while they are staged (registers ->
+// LDS, row pitch 80 B so the per-lane 16-byte fragment reads are conflict free); lane (li, lg) feeds the 8 halves at k = 8 lg ..
+// 8 lg + 7 of a stage to both sides of v_mfma_f32_16x16x32, so any fixed k permutation inside the instruction cancels.
+#define LB_M 128
+#define LB_K 32
+#define LB_P 80
+template <bool F16>
+__global__ __launch_bounds__(256) void k_linear_split(const float* __restrict__ A, int M, int K, const float* __restrict__ W, int Kp,
+                                                     int N16, float* __restrict__ C, int ldc, int accumulate, int npb) {
+  __shared__ __attribute__((aligned(16))) char lds[4 * LB_M * LB_P];
+  char* aH = lds; char* aL = lds + LB_M * LB_P; char* bH = lds + 2 * LB_M * LB_P; char* bL = lds + 3 * LB_M * LB_P;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
+  const int m0 = blockIdx.x * LB_M, n0 = blockIdx.y * npb;
+  const int ncols = min(npb, N16 - n0), nt = ncols >> 4;
+  const int r = t >> 1, h = t & 1;                      // staging: row r, floats 16 h .. 16 h + 15 of the stage
+  const bool arow = m0 + r < M, brow = r < ncols;
+  const float* ap = A + (size_t)(m0 + r) * K + h * 16;
+  const float* bp = W + (size_t)(n0 + r) * Kp + h * 16;
+  float4 ra[4], rb[4];
+  auto load = [&](int kb) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = kb * LB_K + h * 16 + i * 4;
+      ra[i] = (arow && k < K) ? *(const float4*)(ap + kb * LB_K + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rb[i] = brow ? *(const float4*)(bp + kb * LB_K + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store = [&](const float4 (&v)[4], char* hi, char* lo) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float f[8] = {v[2 * q].x, v[2 * q].y, v[2 * q].z, v[2 * q].w, v[2 * q + 1].x, v[2 * q + 1].y, v[2 * q + 1].z, v[2 * q + 1].w};
+      uint4 uh, ul;
+      if (F16) split8_f16(f, uh, ul); else split8(f, uh, ul);
+      *(uint4*)(hi + r * LB_P + h * 32 + q * 16) = uh;
+      *(uint4*)(lo + r * LB_P + h * 32 + q * 16) = ul;
+    }
+  };
+  f32x4 acc[2][8];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nstages = Kp / LB_K;
+  load(0);
+  for (int kb = 0; kb < nstages; ++kb) {
+    __syncthreads();
+    store(ra, aH, aL);
+    store(rb, bH, bL);
+    __syncthreads();
+    if (kb + 1 < nstages) load(kb + 1);
+    uint4 ah[2], al[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ah[i] = *(const uint4*)(aH + (wave * 32 + i * 16 + li) * LB_P + lg * 16);
+      al[i] = *(const uint4*)(aL + (wave * 32 + i * 16 + li) * LB_P + lg * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < nt) {
+        const uint4 bh = *(const uint4*)(bH + (j * 16 + li) * LB_P + lg * 16);
+        const uint4 bl = *(const uint4*)(bL + (j * 16 + li) * LB_P + lg * 16);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          acc[i][j] = mma<F16>(ah[i], bh, acc[i][j]);
+          acc[i][j] = mma<F16>(ah[i], bl, acc[i][j]);
+          acc[i][j] = mma<F16>(al[i], bh, acc[i][j]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < nt) {
+        const int col = n0 + j * 16 + li;
+        if (col < ldc) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int m = m0 + wave * 32 + i * 16 + lg * 4 + q;
+            if (m < M) {
+              float* p = C + (size_t)m * ldc + col;
+              float v = acc[i][j][q];
+              if (accumulate) v += *p;
+              *p = v;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// nullptr-free entry used by md_conv_fwd / md_conv_dgrad for 1x1x1 unit-stride geometries the patch kernels do not take
+int linear_split_launch(int f16, const float* A, int M, int K, const float* W, int Kp, int N16, float* C, int ldc, int accumulate,
+                        hipStream_t s) {
+  if (g_exact_fp32.load()) return MD_ERR_UNSUPPORTED;
+  static const int off = getenv("MD_LINEAR_SPLIT") && atoi(getenv("MD_LINEAR_SPLIT")) == 0;
+  if (off || (K & 3) || (Kp % LB_K) || (N16 & 15)) return MD_ERR_UNSUPPORTED;
+  int npb = 128;
+  while (md_cdiv(M, LB_M) * md_cdiv(N16, npb) < 512 && npb > 32) npb >>= 1;
+  const dim3 grid(md_cdiv(M, LB_M), md_cdiv(N16, npb));
+  if (f16) MD_KLAUNCH(k_linear_split<true>, grid, dim3(256), 0, s, A, M, K, W, Kp, N16, C, ldc, accumulate, npb);
+  else MD_KLAUNCH(k_linear_split<false>, grid, dim3(256), 0, s, A, M, K, W, Kp, N16, C, ldc, accumulate, npb);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}

@@ -57,25 +57,41 @@ __global__ __launch_bounds__(256) void k_add_ln_bwd(const float* __restrict__ do
     dx[row * D + i] = rs * (g - m1 - xhat[row * D + i] * m2) + (dres ? dres[row * D + i] : 0.f);
   }
 }
-// dgamma[i] = sum_rows dout * xhat, dbeta[i] = sum_rows dout   (one thread per feature; blockIdx.y = chunk of rows, in order;
-// with more than one chunk the outputs are per-chunk partials [chunks][D] that k_ln_param_sum adds in chunk order)
-#define LN_CHUNKS 128
+// dgamma[i] = sum_rows dout * xhat, dbeta[i] = sum_rows dout.  Workgroup = 64 features x 4 row lanes over one chunk of rows
+// (blockIdx.y; every lane walks its rows in order, the four lanes are added in a fixed order); with more than one chunk the
+// outputs are per-chunk partials [chunks][D] that k_ln_param_sum adds in a fixed tree.
+#define LN_CHUNKS 256
 __global__ __launch_bounds__(256) void k_ln_param_grad(const float* __restrict__ dout, const float* __restrict__ xhat, int rows, int D,
                                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= D) return;
+  __shared__ float red[2][4][64];
+  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6, i = blockIdx.x * 64 + c;
   const int per = (rows + gridDim.y - 1) / gridDim.y, r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
   float g = 0.f, bsum = 0.f;
-  for (int r = r0; r < r1; ++r) { const float d = dout[(size_t)r * D + i]; g = fmaf(d, xhat[(size_t)r * D + i], g); bsum += d; }
-  dgamma[(size_t)blockIdx.y * D + i] = g; dbeta[(size_t)blockIdx.y * D + i] = bsum;
+  if (i < D)
+    for (int r = r0 + rl; r < r1; r += 4) { const float d = dout[(size_t)r * D + i]; g = fmaf(d, xhat[(size_t)r * D + i], g); bsum += d; }
+  red[0][rl][c] = g; red[1][rl][c] = bsum;
+  __syncthreads();
+  if (rl == 0 && i < D) {
+    dgamma[(size_t)blockIdx.y * D + i] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+    dbeta[(size_t)blockIdx.y * D + i] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+  }
 }
+// 16 features x 16 chunk lanes per workgroup: lane l adds chunks l, l + 16, ... in order, then the 16 lanes in order
 __global__ __launch_bounds__(256) void k_ln_param_sum(const float* __restrict__ pg, const float* __restrict__ pb, int chunks, int D,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= D) return;
+  __shared__ float red[2][16][16];
+  const int c = threadIdx.x & 15, l = threadIdx.x >> 4, i = blockIdx.x * 16 + c;
   float g = 0.f, b = 0.f;
-  for (int c = 0; c < chunks; ++c) { g += pg[(size_t)c * D + i]; b += pb[(size_t)c * D + i]; }
-  dgamma[i] = g; dbeta[i] = b;
+  if (i < D)
+    for (int k = l; k < chunks; k += 16) { g += pg[(size_t)k * D + i]; b += pb[(size_t)k * D + i]; }
+  red[0][l][c] = g; red[1][l][c] = b;
+  __syncthreads();
+  if (l == 0 && i < D) {
+    float sg = 0.f, sb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { sg += red[0][k][c]; sb += red[1][k][c]; }
+    dgamma[i] = sg; dbeta[i] = sb;
+  }
 }
 
 // Attention core.  qkv [S][B][3*D] (q | k | v as nn.MultiheadAttention's in_proj lays them out), head h uses features
@@ -570,13 +586,13 @@ extern "C" int md_add_layernorm_bwd(const float* dout, const float* gamma, const
   MD_KLAUNCH(k_add_ln_bwd, dim3((unsigned)rows), dim3(256), 0, s, dout, gamma, xhat, rstd, dres, D, dx);
   MD_CHECK_LAUNCH();
   if (!chunked) {
-    MD_KLAUNCH(k_ln_param_grad, dim3(md_cdiv(D, 256), 1), dim3(256), 0, s, dout, xhat, (int)rows, D, dgamma, dbeta);
+    MD_KLAUNCH(k_ln_param_grad, dim3(md_cdiv(D, 64), 1), dim3(256), 0, s, dout, xhat, (int)rows, D, dgamma, dbeta);
     MD_CHECK_LAUNCH();
   } else {
     float* pg = scratch; float* pb = scratch + (size_t)LN_CHUNKS * D;
-    MD_KLAUNCH(k_ln_param_grad, dim3(md_cdiv(D, 256), LN_CHUNKS), dim3(256), 0, s, dout, xhat, (int)rows, D, pg, pb);
+    MD_KLAUNCH(k_ln_param_grad, dim3(md_cdiv(D, 64), LN_CHUNKS), dim3(256), 0, s, dout, xhat, (int)rows, D, pg, pb);
     MD_CHECK_LAUNCH();
-    MD_KLAUNCH(k_ln_param_sum, dim3(md_cdiv(D, 256)), dim3(256), 0, s, (const float*)pg, (const float*)pb, LN_CHUNKS, D, dgamma, dbeta);
+    MD_KLAUNCH(k_ln_param_sum, dim3(md_cdiv(D, 16)), dim3(256), 0, s, (const float*)pg, (const float*)pb, LN_CHUNKS, D, dgamma, dbeta);
     MD_CHECK_LAUNCH();
   }
   return MD_OK;

@@ -385,9 +385,23 @@ extern "C" int md_channel_bias_fwd(const float* x, const float* bias, int32_t N,
   MD_CHECK_LAUNCH();
   return MD_OK;
 }
+// L == 1 and few rows (a table broadcast over the batch: ViViT's positional embedding, 794 k "channels" x 4 clips): one thread
+// per channel, rows in order, coalesced across channels.
+__global__ __launch_bounds__(256) void k_channel_bias_bwd_rows(const float* __restrict__ dout, int Nn, int Cc, float* __restrict__ db) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= Cc) return;
+  float s = 0.f;
+  for (int n = 0; n < Nn; ++n) s += dout[(size_t)n * Cc + c];
+  db[c] = s;
+}
 extern "C" int md_channel_bias_bwd(const float* dout, int32_t N, int32_t C, int32_t L, float* dbias, void* stream) {
   if (!dout || !dbias) return MD_ERR_NULL;
   if (N <= 0 || C <= 0 || L <= 0) return MD_ERR_BAD_SHAPE;
+  if (L == 1 && N <= 64 && C >= 4096) {
+    MD_KLAUNCH(k_channel_bias_bwd_rows, dim3(md_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, dout, N, C, dbias);
+    MD_CHECK_LAUNCH();
+    return MD_OK;
+  }
   MD_KLAUNCH(k_channel_bias_bwd, dim3(C), dim3(256), 0, (hipStream_t)stream, dout, N, C, L, dbias);
   MD_CHECK_LAUNCH();
   return MD_OK;

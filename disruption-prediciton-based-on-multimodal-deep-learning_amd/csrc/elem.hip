@@ -394,9 +394,48 @@ __global__ __launch_bounds__(256) void k_channel_bias_bwd_rows(const float* __re
   for (int n = 0; n < Nn; ++n) s += dout[(size_t)n * Cc + c];
   db[c] = s;
 }
-extern "C" int md_channel_bias_bwd(const float* dout, int32_t N, int32_t C, int32_t L, float* dbias, void* stream) {
+// L == 1 and many rows (a Linear bias over 16 548 tokens): column sums in two fixed-order levels.  Level 1: workgroup = 64
+// columns x 4 row lanes over one of CB_CHUNKS row chunks -> partial [chunk][C]; level 2: 16 columns x 16 chunk lanes.
+#define CB_CHUNKS 128
+__global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ dout, int rows, int Cc, float* __restrict__ part) {
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6, i = blockIdx.x * 64 + c;
+  const int per = (rows + gridDim.y - 1) / gridDim.y, r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+  float s = 0.f;
+  if (i < Cc)
+    for (int r = r0 + rl; r < r1; r += 4) s += dout[(size_t)r * Cc + i];
+  red[rl][c] = s;
+  __syncthreads();
+  if (rl == 0 && i < Cc) part[(size_t)blockIdx.y * Cc + i] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+__global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ part, int chunks, int Cc, float* __restrict__ db) {
+  __shared__ float red[16][16];
+  const int c = threadIdx.x & 15, l = threadIdx.x >> 4, i = blockIdx.x * 16 + c;
+  float s = 0.f;
+  if (i < Cc)
+    for (int k = l; k < chunks; k += 16) s += part[(size_t)k * Cc + i];
+  red[l][c] = s;
+  __syncthreads();
+  if (l == 0 && i < Cc) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][c];
+    db[i] = t;
+  }
+}
+extern "C" size_t md_channel_bias_bwd_scratch_floats(int32_t N, int32_t C, int32_t L) {
+  return (L == 1 && N >= 2048) ? (size_t)CB_CHUNKS * (size_t)C : 0;
+}
+extern "C" int md_channel_bias_bwd(const float* dout, int32_t N, int32_t C, int32_t L, float* dbias, float* scratch, void* stream) {
   if (!dout || !dbias) return MD_ERR_NULL;
   if (N <= 0 || C <= 0 || L <= 0) return MD_ERR_BAD_SHAPE;
+  if (scratch && md_channel_bias_bwd_scratch_floats(N, C, L)) {
+    MD_KLAUNCH(k_colsum_partial, dim3(md_cdiv(C, 64), CB_CHUNKS), dim3(256), 0, (hipStream_t)stream, dout, N, C, scratch);
+    MD_CHECK_LAUNCH();
+    MD_KLAUNCH(k_colsum_final, dim3(md_cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, CB_CHUNKS, C, dbias);
+    MD_CHECK_LAUNCH();
+    return MD_OK;
+  }
   if (L == 1 && N <= 64 && C >= 4096) {
     MD_KLAUNCH(k_channel_bias_bwd_rows, dim3(md_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, dout, N, C, dbias);
     MD_CHECK_LAUNCH();

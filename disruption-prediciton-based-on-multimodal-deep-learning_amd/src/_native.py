@@ -92,7 +92,8 @@ SIGNATURES = {
     "md_rowmean_fwd": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P]),
     "md_rowmean_bwd": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P]),
     "md_channel_bias_fwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P]),
-    "md_channel_bias_bwd": (C.c_int, [_P, _I32, _I32, _I32, _P, _P]),
+    "md_channel_bias_bwd": (C.c_int, [_P, _I32, _I32, _I32, _P, _P, _P]),
+    "md_channel_bias_bwd_scratch_floats": (_SZ, [_I32, _I32, _I32]),
     "md_seq_sum_fwd": (C.c_int, [_P, _I32, _I32, _I32, _F, _P, _P]),
     "md_seq_sum_bwd": (C.c_int, [_P, _I32, _I32, _I32, _F, _P, _P]),
     "md_add_layernorm_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int64, _I32, _F, _P, _P, _P, _P, _P]),

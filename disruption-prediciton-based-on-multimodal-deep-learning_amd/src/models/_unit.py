@@ -268,7 +268,9 @@ class _ChannelBias(torch.autograd.Function):
         Nn, Cc, L = ctx.shape
         g = ops.f32(dout).contiguous()
         db = torch.empty(Cc, device=g.device)
-        N.check(N.lib().md_channel_bias_bwd(ops._p(g), Nn, Cc, L, ops._p(db), ops._stream()), "md_channel_bias_bwd")
+        ns = N.lib().md_channel_bias_bwd_scratch_floats(Nn, Cc, L)
+        scratch = torch.empty(ns, device=g.device) if ns else None
+        N.check(N.lib().md_channel_bias_bwd(ops._p(g), Nn, Cc, L, ops._p(db), ops._p(scratch), ops._stream()), "md_channel_bias_bwd")
         return g, db
 
 

@@ -212,7 +212,9 @@ int md_rowmean_bwd(const float* dmean, int64_t rows, int64_t thw, float* dx, voi
 /* Per-channel bias on an (N,C,L) tensor (a Conv1d bias that is not absorbed by a following normalisation,
  * src/models/CnnLSTM.py:42) and its gradient db[c] = sum_{n,l} dout. */
 int md_channel_bias_fwd(const float* x, const float* bias, int32_t N, int32_t C, int32_t L, float* out, void* stream);
-int md_channel_bias_bwd(const float* dout, int32_t N, int32_t C, int32_t L, float* dbias, void* stream);
+size_t md_channel_bias_bwd_scratch_floats(int32_t N, int32_t C, int32_t L);   /* 0: no scratch needed */
+int md_channel_bias_bwd(const float* dout, int32_t N, int32_t C, int32_t L, float* dbias, float* scratch /* may be NULL: the
+                        one-workgroup-per-channel form is used */, void* stream);
 /* out[b][d] = scale * sum_s x[b][s][d] and its adjoint: what CnnLSTM's attention pooling (:76-97) evaluates to -- the
  * softmax is taken over the same axis the result is averaged over, so every step gets weight 1/H (see src/models/CnnLSTM.py). */
 int md_seq_sum_fwd(const float* x, int32_t B, int32_t S, int32_t D, float scale, float* out, void* stream);

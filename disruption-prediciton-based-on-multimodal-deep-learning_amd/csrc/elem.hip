@@ -467,3 +467,39 @@ extern "C" int md_mask_scale(const float* x, const float* mask, float scale, int
   MD_CHECK_LAUNCH();
   return MD_OK;
 }
+
+
+// Device-side tail of DatasetForVideo.get_video_data (reference src/dataset.py:124-144 without the cv2 augmentations): centre
+// crop (:241-246), BGR mean subtraction (:203-207) and (T,H,W,C) -> (C,T,H,W) (:229-230), from the uint8 frames cv2.imread
+// returns.  frames [B][T][Hr][Wr][3] uint8; layout 0: out [B][3][T][S][S] fp32 (the module-boundary layout); layout 1:
+// out [B][T][S][S][4] fp32, channel 3 = 0 (the kernels' channels-last layout: skips md_nchw_to_cl).  One thread per output
+// pixel: 3 bytes in, 12-16 bytes out (HBM-bound byte kernel, no reuse).
+__global__ __launch_bounds__(256) void k_clip_preprocess(const unsigned char* __restrict__ frames, int B, int T, int Hr, int Wr, int S,
+                                                        int y0, int x0, float m0, float m1, float m2, int layout,
+                                                        float* __restrict__ out) {
+  const int64_t n = (int64_t)B * T * S * S;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const int x = (int)(e % S); int64_t r = e / S;
+    const int y = (int)(r % S); r /= S;
+    const int t = (int)(r % T), b = (int)(r / T);
+    const unsigned char* px = frames + ((((int64_t)b * T + t) * Hr + (y0 + y)) * Wr + (x0 + x)) * 3;
+    const float v0 = (float)px[0] - m0, v1 = (float)px[1] - m1, v2 = (float)px[2] - m2;
+    if (layout == 0) {
+      const int64_t plane = (int64_t)T * S * S, o = (int64_t)b * 3 * plane + ((int64_t)t * S + y) * S + x;
+      out[o] = v0; out[o + plane] = v1; out[o + 2 * plane] = v2;
+    } else {
+      *(float4*)(out + e * 4) = make_float4(v0, v1, v2, 0.f);
+    }
+  }
+}
+extern "C" int md_clip_preprocess(const uint8_t* frames, int32_t B, int32_t T, int32_t Hr, int32_t Wr, int32_t S, const float* mean_bgr,
+                                  int32_t layout, float* out, void* stream) {
+  if (!frames || !mean_bgr || !out) return MD_ERR_NULL;
+  if (B <= 0 || T <= 0 || Hr <= 0 || Wr <= 0 || S <= 0 || (S & 1) || S > Hr || S > Wr || (layout != 0 && layout != 1)) return MD_ERR_BAD_SHAPE;
+  const int64_t n = (int64_t)B * T * S * S;
+  int64_t blocks = (n + 255) / 256; if (blocks > 65536) blocks = 65536;
+  MD_KLAUNCH(k_clip_preprocess, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, frames, B, T, Hr, Wr, S, Hr / 2 - S / 2,
+             Wr / 2 - S / 2, mean_bgr[0], mean_bgr[1], mean_bgr[2], layout, out);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}

@@ -244,6 +244,12 @@ int md_attention_bwd(const float* qkv, const float* probs, const float* drop, co
 /* ELU (src/models/ViViT.py:166): with dy != NULL the call returns dy * elu'(x).  alpha = 0 is ReLU (MultiModal.py:23,29). */
 int md_elu(const float* x, const float* dy, float alpha, int64_t n, float* out, void* stream);
 int md_gelu(const float* x, const float* dy, int32_t kind, int64_t n, float* out, void* stream);
+/* Device-side tail of DatasetForVideo.get_video_data (src/dataset.py:124-144, without the cv2 augmentations): centre crop of
+ * S x S (rows Hr/2 - S/2 .., columns Wr/2 - S/2 .., :241-246; S even), subtraction of the BGR means (:203-207, host array of 3)
+ * and the (T,H,W,C) -> (C,T,H,W) transpose (:229-230) from uint8 frames [B][T][Hr][Wr][3].  layout 0: out [B][3][T][S][S];
+ * layout 1: out [B][T][S][S][4] with channel 3 = 0 (the kernels' channels-last layout).  Exact: uint8 -> fp32 minus the mean. */
+int md_clip_preprocess(const uint8_t* frames, int32_t B, int32_t T, int32_t Hr, int32_t Wr, int32_t S, const float* mean_bgr,
+                       int32_t layout, float* out, void* stream);
 /* Tensor fusion of TFN / TFN_GB (src/models/MultiModal.py:214-220, 301-307): out [B][(Da+1)*(Dc+1)] = [1 | a[b]] (x) [1 | c[b]]
  * (what the reference builds with torch.cat of ones + torch.bmm); the backward returns da [B][Da], dc [B][Dc]. */
 int md_outer_fwd(const float* a, const float* c, int32_t B, int32_t Da, int32_t Dc, float* out, void* stream);

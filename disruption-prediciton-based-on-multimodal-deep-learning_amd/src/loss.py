@@ -91,7 +91,7 @@ class LDAMLoss(nn.Module):
         self.m_list = torch.FloatTensor(m_list)
 
     def forward(self, x: torch.Tensor, target: torch.Tensor):
-        m = self.m_list.to(device=x.device, dtype=torch.float32).contiguous()
+        m = _dev_weight(self.m_list, x.device)               # margins: uploaded once per update_m_list, not per call
         return _SoftmaxLossFunction.apply(x, target, _dev_weight(self.weight, x.device), m, "ldam", float(self.s), self)
 
 

@@ -42,6 +42,10 @@ for _ in range(steps):
     loss = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
 print(f"cfg4 fused R2Plus1D+Transformer GB step, B=8: {dt * 1e3:.2f} ms/step  ({8 / dt:.1f} clips/s)  loss {float(loss.detach()):.4f}")
+import json
+print(json.dumps({"metric": "clips/sec (full step) R2Plus1D + Transformer-0D, GradientBlending", "value": round(8 / dt, 1), "unit": "clips/s",
+                  "n_gpus": 1, "steps": steps, "warmup": 3, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "data": "synthetic",
+                  "config": {"workload": "BASELINE configs[3] on ONE GPU: R2Plus1D [1,2,2,1] (8,3,21,128,128) + Transformer-0D (18 features, d 128, L4, H8, FF1024, dropout 0.1), FusionGB, GradientBlending(0.1/0.4/0.5) over Focal, ClipAdamW(2e-4, clip 1.0)"}}))
 if os.environ.get("CFG4_PROFILE"):
     from torch.profiler import profile, ProfilerActivity
     with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:

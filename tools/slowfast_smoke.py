@@ -24,3 +24,13 @@ for _ in range(3): step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
 print(f"SlowFast B={B}: loss {float(loss):.4f}, {len(list(m.parameters()))} parameter tensors all with finite gradients, "
       f"{dt*1e3:.1f} ms/step = {B/dt:.1f} clips/s, peak memory {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
+if os.environ.get("SF_PROFILE"):
+    from torch.profiler import profile, ProfilerActivity
+    for _ in range(5): step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): step()
+    torch.cuda.synchronize(); print(f"steady: {(time.perf_counter() - t0) / 10 * 1e3:.2f} ms/step")
+    with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+        step(); torch.cuda.synchronize()
+    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=22, max_name_column_width=60))
+    print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=10, max_name_column_width=60))

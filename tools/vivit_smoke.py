@@ -30,7 +30,12 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(steps):
     loss = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
-print(f"ViViT cfg3 B=4: {dt * 1e3:.2f} ms/step  ({4 / dt:.1f} clips/s)  loss {float(loss):.4f}")
+print(f"ViViT cfg3 B=4: {dt * 1e3:.2f} ms/step  ({4 / dt:.1f} clips/s)  loss {float(loss.detach()):.4f}")
+import json
+print(json.dumps({"metric": "clips/sec (fwd+bwd) ViViT cfg3", "value": round(4 / dt, 1), "unit": "clips/s", "n_gpus": 1, "steps": steps,
+                  "warmup": 3, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "dtype": "f32 (attention: fp32 MFMA; Linears: 3 fp16/bf16 MFMAs on hi+lo splits)",
+                  "data": "synthetic", "alg_tflops": round(4 / dt * 27.1e9 / 1e12, 2),
+                  "config": {"workload": "BASELINE configs[2]: ViViT (B=4,3,21,224,224), patch 16, dim 128, depth 2, heads 4, d_head 64, scale_dim 8, pool mean, dropout 0.1; forward + FocalLoss + backward (no optimizer step)"}}))
 if os.environ.get("VIVIT_PROFILE"):
     from torch.profiler import profile, ProfilerActivity
     with profile(activities=[ProfilerActivity.CUDA]) as prof:

@@ -44,6 +44,17 @@ def _param_table(m: nn.Module):
     print("\n".join(rows + ["total parameters: %d" % sum(p.numel() for p in m.parameters())]))
 
 
+def _make_connector(d_in: int, d_out: int) -> nn.Sequential:
+    """Linear, ReLU - children 0 and 1, as the reference's ``connector``."""
+    return nn.Sequential(nn.Linear(d_in, d_out), nn.ReLU())
+
+
+def _make_classifier(d_in: int, d_hidden: int, n_classes: int, norm: str = "layer") -> nn.Sequential:
+    """Linear, LayerNorm (BatchNorm1d for TFN_GB), ReLU, Linear - children 0..3, as the reference's ``classifier``."""
+    mid = nn.LayerNorm(d_hidden) if norm == "layer" else nn.BatchNorm1d(d_hidden)
+    return nn.Sequential(nn.Linear(d_in, d_hidden), mid, nn.ReLU(), nn.Linear(d_hidden, n_classes))
+
+
 class _NoHook:
     def remove(self):
         pass
@@ -57,18 +68,9 @@ class MultiModalModel(nn.Module):
         self.args_0D = args_0D
         self.encoder_video = ViViTEncoder(**args_video)
         self.encoder_0D = TransformerEncoder(**args_0D)
-        linear_input_dims = self.encoder_0D.feature_dims + self.encoder_video.dim
-
-        self.connector = nn.Sequential(
-            nn.Linear(linear_input_dims, linear_input_dims // 2),
-            nn.ReLU()
-        )
-        self.classifier = nn.Sequential(
-            nn.Linear(linear_input_dims // 2, linear_input_dims // 2),
-            nn.LayerNorm(linear_input_dims // 2),
-            nn.ReLU(),
-            nn.Linear(linear_input_dims // 2, n_classes)
-        )
+        width = self.encoder_0D.feature_dims + self.encoder_video.dim          # concatenated latents
+        self.connector = _make_connector(width, width // 2)
+        self.classifier = _make_classifier(width // 2, width // 2, n_classes)
 
     def forward(self, x_video: torch.Tensor, x_0D: torch.Tensor):
         x = torch.cat([self.encoder_video(x_video), self.encoder_0D(x_0D)], axis=1)
@@ -94,18 +96,9 @@ class MultiModalModel_GB(nn.Module):
         self.args_0D = args_0D
         self.vis_model = ViViT(**args_video)
         self.ts_model = Transformer(**args_0D)
-        linear_input_dims = self.ts_model.feature_dims + self.vis_model.dim
-
-        self.connector = nn.Sequential(
-            nn.Linear(linear_input_dims, linear_input_dims // 2),
-            nn.ReLU()
-        )
-        self.classifier = nn.Sequential(
-            nn.Linear(linear_input_dims // 2, linear_input_dims // 2),
-            nn.LayerNorm(linear_input_dims // 2),
-            nn.ReLU(),
-            nn.Linear(linear_input_dims // 2, n_classes)
-        )
+        width = self.ts_model.feature_dims + self.vis_model.dim
+        self.connector = _make_connector(width, width // 2)
+        self.classifier = _make_classifier(width // 2, width // 2, n_classes)
         self.vis_latent = None
         self.ts_latent = None
         self.vis_hook = _NoHook()
@@ -119,18 +112,8 @@ class MultiModalModel_GB(nn.Module):
     def update_use_stream(self, use_stream: Literal["video", "0D", "multi", "multi-GB"]):
         # the reference flips only the top-level .training flags of the three children (:83-93, :106-119)
         self.use_stream = use_stream
-        if use_stream == 'video':
-            self.ts_model.training = False
-            self.vis_model.training = True
-            self.classifier.training = False
-        elif use_stream == '0D':
-            self.ts_model.training = True
-            self.vis_model.training = False
-            self.classifier.training = False
-        else:
-            self.ts_model.training = True
-            self.vis_model.training = True
-            self.classifier.training = True
+        ts_on, vis_on, cls_on = {"video": (False, True, False), "0D": (True, False, False)}.get(use_stream, (True, True, True))
+        self.ts_model.training, self.vis_model.training, self.classifier.training = ts_on, vis_on, cls_on
 
     def _both(self, x_vis, x_ts):
         vis_latent = self.vis_model._encode(x_vis)
@@ -186,16 +169,8 @@ class TFN(nn.Module):
         self.fusion_input_dims = (self.encoder_0D_dim + 1) * (self.encoder_video_dim + 1)
         self.linear_input_dims = self.encoder_0D_dim + self.encoder_video_dim
 
-        self.connector = nn.Sequential(
-            nn.Linear(self.fusion_input_dims, self.linear_input_dims),
-            nn.ReLU()
-        )
-        self.classifier = nn.Sequential(
-            nn.Linear(self.linear_input_dims, self.linear_input_dims // 2),
-            nn.LayerNorm(self.linear_input_dims // 2),
-            nn.ReLU(),
-            nn.Linear(self.linear_input_dims // 2, n_classes)
-        )
+        self.connector = _make_connector(self.fusion_input_dims, self.linear_input_dims)
+        self.classifier = _make_classifier(self.linear_input_dims, self.linear_input_dims // 2, n_classes)
 
     def forward(self, x_vis: torch.Tensor, x_0D: torch.Tensor):
         fusion = OuterFusionFunction.apply(self.encoder_video(x_vis), self.encoder_0D(x_0D))
@@ -230,12 +205,7 @@ class TFN_GB(nn.Module):
         self.fusion_input_dims = (self.network_0D_dims + 1) * (self.network_video_dims + 1)
 
         self.dropout = nn.Dropout(0)
-        self.classifier = nn.Sequential(
-            nn.Linear(self.fusion_input_dims, self.fusion_input_dims // 2),
-            nn.BatchNorm1d(self.fusion_input_dims // 2),
-            nn.ReLU(),
-            nn.Linear(self.fusion_input_dims // 2, n_classes)
-        )
+        self.classifier = _make_classifier(self.fusion_input_dims, self.fusion_input_dims // 2, n_classes, norm="batch")
         self.h_vis = None
         self.h_0D = None
         self.vis_hook = _NoHook()

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from .MLSTM_FCN import MLSTM_FCN
-from .MultiModal import _classifier, _connector, _param_table
+from .MultiModal import _classifier, _connector, _make_classifier, _make_connector, _param_table
 from .R2Plus1D import R2Plus1DClassifier, R2Plus1DNet
 from .slowfast import SlowFast
 from .transformer import Transformer
@@ -49,16 +49,8 @@ class FusionGB(nn.Module):
         self._vis = _vision_adapter(vis_model)
         self._ts = _ts_adapter(ts_model)
         linear_input_dims = self._ts[2] + self._vis[2]
-        self.connector = nn.Sequential(
-            nn.Linear(linear_input_dims, linear_input_dims // 2),
-            nn.ReLU()
-        )
-        self.classifier = nn.Sequential(
-            nn.Linear(linear_input_dims // 2, linear_input_dims // 2),
-            nn.LayerNorm(linear_input_dims // 2),
-            nn.ReLU(),
-            nn.Linear(linear_input_dims // 2, n_classes)
-        )
+        self.connector = _make_connector(linear_input_dims, linear_input_dims // 2)
+        self.classifier = _make_classifier(linear_input_dims // 2, linear_input_dims // 2, n_classes)
         self.vis_latent = None
         self.ts_latent = None
         self.use_stream = use_stream

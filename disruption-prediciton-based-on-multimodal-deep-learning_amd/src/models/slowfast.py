@@ -17,23 +17,23 @@ from .resnet import Bottleneck3D, ResNet3D
 from ._unit import GlobalAvgPoolFunction, HeadFunction, conv_plain
 
 
+_STAGES = ("layer1", "layer2", "layer3", "layer4")
+_LATERALS = ("l_maxpool", "l_layer1", "l_layer2", "l_layer3")          # one per point where the fast path feeds the slow one
+
+
 class SlowNet(ResNet3D):
+    """Slow pathway: before every stage the lateral tensor of the fast pathway is concatenated on the channel axis."""
+
     def __init__(self, blocks, layers, **kwargs):
         super(SlowNet, self).__init__(blocks, layers, **kwargs)
         self.init_params()
 
     def forward(self, x: Tuple[torch.Tensor, List[torch.Tensor]]):
-        x, laterals = x
-        x = self.stem(x)
-        x = torch.cat([x, laterals[0]], dim=1)
-        x = self.layer1(x)
-        x = torch.cat([x, laterals[1]], dim=1)
-        x = self.layer2(x)
-        x = torch.cat([x, laterals[2]], dim=1)
-        x = self.layer3(x)
-        x = torch.cat([x, laterals[3]], dim=1)
-        x = self.layer4(x)
-        return GlobalAvgPoolFunction.apply(x)
+        h, laterals = x
+        h = self.stem(h)
+        for name, lat in zip(_STAGES, laterals):
+            h = getattr(self, name)(torch.cat([h, lat], dim=1))
+        return GlobalAvgPoolFunction.apply(h)
 
 
 def resnet50_s(block=Bottleneck3D, layers=[3, 4, 6, 3], **kwargs):
@@ -41,35 +41,24 @@ def resnet50_s(block=Bottleneck3D, layers=[3, 4, 6, 3], **kwargs):
 
 
 class FastNet(ResNet3D):
+    """Fast pathway plus the four time-strided lateral convolutions (kernel (alpha+2,1,1), stride (alpha,1,1), no bias) that
+    bring its stem / stage outputs to the slow pathway's frame rate."""
+
     def __init__(self, blocks, layers, **kwargs):
         super(FastNet, self).__init__(blocks, layers, **kwargs)
-        alpha = kwargs["alpha"]
-        kernel_size = (alpha + 2, 1, 1)
-        stride = (alpha, 1, 1)
-        padding = (1, 0, 0)
-        m = 16
-        self.l_maxpool = nn.Conv3d(m // self.alpha, m // self.alpha, kernel_size=kernel_size, stride=stride, bias=False,
-                                   padding=padding)
-        self.l_layer1 = nn.Conv3d(4 * m // self.alpha, 4 * m // self.alpha, kernel_size=kernel_size, stride=stride, bias=False,
-                                  padding=padding)
-        self.l_layer2 = nn.Conv3d(8 * m // self.alpha, 8 * m // self.alpha, kernel_size=kernel_size, stride=stride, bias=False,
-                                  padding=padding)
-        self.l_layer3 = nn.Conv3d(16 * m // self.alpha, 16 * m // self.alpha, kernel_size=kernel_size, stride=stride,
-                                  bias=False, padding=padding)
+        a = kwargs["alpha"]
+        for name, mult in zip(_LATERALS, (1, 4, 8, 16)):
+            width = mult * 16 // self.alpha
+            setattr(self, name, nn.Conv3d(width, width, kernel_size=(a + 2, 1, 1), stride=(a, 1, 1), padding=(1, 0, 0), bias=False))
         self.init_params()
 
     def forward(self, x: torch.Tensor):
-        laterals = []
-        x = self.stem(x)
-        laterals.append(conv_plain(x, self.l_maxpool))
-        x = self.layer1(x)
-        laterals.append(conv_plain(x, self.l_layer1))
-        x = self.layer2(x)
-        laterals.append(conv_plain(x, self.l_layer2))
-        x = self.layer3(x)
-        laterals.append(conv_plain(x, self.l_layer3))
-        x = self.layer4(x)
-        return GlobalAvgPoolFunction.apply(x), laterals
+        h = self.stem(x)
+        laterals = [conv_plain(h, self.l_maxpool)]
+        for name, lat in zip(_STAGES[:3], _LATERALS[1:]):
+            h = getattr(self, name)(h)
+            laterals.append(conv_plain(h, getattr(self, lat)))
+        return GlobalAvgPoolFunction.apply(self.layer4(h)), laterals
 
 
 def resnet50_f(block=Bottleneck3D, layers=[3, 4, 6, 3], **kwargs):

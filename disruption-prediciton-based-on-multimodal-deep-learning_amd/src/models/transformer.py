@@ -26,15 +26,12 @@ class PositionalEncoding(nn.Module):
         super(PositionalEncoding, self).__init__()
         self.d_model = d_model
         self.max_len = max_len
-        pe = torch.zeros(max_len, d_model).float()
-        position = torch.arange(0, max_len).float().unsqueeze(1)
-        div_term = (torch.arange(0, d_model, 2).float() * -(math.log(10000.0) / d_model)).exp()
-        pe[:, 0::2] = torch.sin(position * div_term)
-        if d_model % 2 != 0:
-            pe[:, 1::2] = torch.cos(position * div_term)[:, 0:-1]
-        else:
-            pe[:, 1::2] = torch.cos(position * div_term)
-        pe = pe.unsqueeze(0).transpose(0, 1)          # (max_len, 1, d_model)
+        # sin on the even features, cos on the odd ones, wavelengths 10000^(2i/d); built as (max_len, 1, d_model) directly
+        steps = torch.arange(max_len, dtype=torch.float32)[:, None]
+        rates = torch.exp(torch.arange(0, d_model, 2, dtype=torch.float32) * -(math.log(10000.0) / d_model))
+        pe = torch.zeros(max_len, 1, d_model)
+        pe[:, 0, 0::2] = torch.sin(steps * rates)
+        pe[:, 0, 1::2] = torch.cos(steps * rates)[:, : d_model // 2]
         self.register_buffer('pe', pe)
 
     def forward(self, x: torch.Tensor):
@@ -59,25 +56,17 @@ class TransformerEncoder(nn.Module):
         self.max_len = max_len
         self.feature_dims = feature_dims
         self.noise = NoiseLayer(mean=0, std=1e-3)
-        if kernel_size // 2 == 0:
+        if kernel_size // 2 == 0:            # (sic) the reference's check: only kernel_size 1 is bumped, to 2
             print("kernel sholud be odd number")
             kernel_size += 1
-        padding = (kernel_size - 1) // 2
-        self.filter = nn.Sequential(
-            nn.Conv1d(in_channels=n_features, out_channels=feature_dims, kernel_size=kernel_size, stride=1, padding=padding),
-            nn.Conv1d(in_channels=feature_dims, out_channels=feature_dims, kernel_size=kernel_size, stride=1, padding=padding),
-            nn.BatchNorm1d(feature_dims),
-            nn.ReLU(),
-        )
+        same = dict(kernel_size=kernel_size, stride=1, padding=(kernel_size - 1) // 2)
+        self.filter = nn.Sequential(nn.Conv1d(n_features, feature_dims, **same), nn.Conv1d(feature_dims, feature_dims, **same),
+                                    nn.BatchNorm1d(feature_dims), nn.ReLU())
         self.pos_enc = PositionalEncoding(d_model=feature_dims, max_len=max_len)
         encoder = nn.TransformerEncoderLayer(d_model=feature_dims, nhead=n_heads, dropout=dropout, dim_feedforward=dim_feedforward,
                                              activation=GELU())
         self.transformer_encoder = nn.TransformerEncoder(encoder, num_layers=n_layers)
-        self.connector = nn.Sequential(
-            nn.Linear(feature_dims, feature_dims),
-            nn.LayerNorm(feature_dims),
-            nn.GELU()
-        )
+        self.connector = nn.Sequential(nn.Linear(feature_dims, feature_dims), nn.LayerNorm(feature_dims), nn.GELU())
 
     # -- one nn.TransformerEncoderLayer (norm_first = False): x = norm1(x + drop(SA(x))); x = norm2(x + drop(FF(x)))
     def _layer(self, x, layer, mask):
@@ -136,12 +125,7 @@ class Transformer(nn.Module):
         self.max_len = max_len
         self.n_features = n_features
         self.encoder = TransformerEncoder(n_features, kernel_size, feature_dims, max_len, n_layers, n_heads, dim_feedforward, dropout)
-        self.classifier = nn.Sequential(
-            nn.Linear(feature_dims, cls_dims),
-            nn.LayerNorm(cls_dims),
-            GELU(),
-            nn.Linear(cls_dims, n_classes)
-        )
+        self.classifier = nn.Sequential(nn.Linear(feature_dims, cls_dims), nn.LayerNorm(cls_dims), GELU(), nn.Linear(cls_dims, n_classes))
 
     def encode(self, x: torch.Tensor):
         with torch.no_grad():

@@ -133,3 +133,31 @@ def test_wide_linear_matches_fp64(rows, din, dout):
     assert rel(xg.grad, xr.grad) < 2e-5
     assert rel(wg.grad, wr.grad) < 2e-5
     assert rel(bg.grad, br.grad) < 2e-5
+
+
+@pytest.mark.gpu
+def test_single_head_identity_projection_and_long_sequences():
+    """Attention with n_heads == 1 and d_head == dim has no output projection (ViViT.py:60,66-69: nn.Identity); checked against
+    the oracle restatement on the module's own random state.  Sequences beyond the matrix-core kernels' 256 tokens fall back to the
+    row-blocked kernels (checked against PyTorch), beyond their LDS budget the call fails loudly."""
+    from src.models.ViViT import ViViT
+    from src.models._unit import AttentionFunction
+    torch.manual_seed(12)
+    m = ViViT(image_size=16, patch_size=8, n_frames=3, n_classes=2, dim=16, depth=1, n_heads=1, pool="cls", in_channels=3, d_head=16,
+              dropout=0.0, embedd_dropout=0.0, scale_dim=2).cuda().train()
+    assert isinstance(m.space_transformer.layers[0][0].fn.to_out, torch.nn.Identity)
+    x = torch.randn(2, 3, 3, 16, 16)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    ref = ov.vivit_forward(x, sd, 8, 1, 1, "cls", 3, 1.0)
+    out = m(x.cuda())
+    assert float((out.detach().cpu() - ref).abs().max()) <= 1e-3 * max(1.0, float(ref.abs().max()))
+    out.sum().backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+    S, B, D, H = 300, 1, 32, 2
+    qkv = torch.randn(B, S, 3 * D)
+    q, k, v = (t.reshape(B, S, H, D // H).transpose(1, 2) for t in qkv.chunk(3, dim=-1))
+    ref = (torch.softmax(q @ k.transpose(2, 3) / (D // H) ** 0.5, dim=-1) @ v).transpose(1, 2).reshape(B, S, D)
+    got = AttentionFunction.apply(qkv.cuda(), None, H, None, True)
+    assert float((got.cpu() - ref).abs().max()) < 3e-6
+    with pytest.raises(RuntimeError):
+        AttentionFunction.apply(torch.randn(1, 1200, 3 * D).cuda(), None, H, None, True)

@@ -12,6 +12,11 @@ m = SlowFast(input_shape=(3, 32, 224, 224), layers=[1, 2, 2, 1], alpha=4, tau_fa
 loss_fn = LDAMLoss(cls_num_list=[100, 2000], max_m=0.5, s=1.0, weight=None)
 x = torch.randn(B, 3, 32, 224, 224, device=dev) * 50
 y = (torch.arange(B) % 2).to(dev)
+# with SF_GRAPH the eager reference runs on a side stream: a HIP-graph capture after model steps on the legacy default stream
+# crashes in hipStreamEndCapture on this stack (see src/utils/graphed.py)
+_side = torch.cuda.Stream() if os.environ.get('SF_GRAPH') else None
+if _side is not None:
+    _side.wait_stream(torch.cuda.current_stream()); torch.cuda.set_stream(_side)
 def step():
     m.zero_grad(set_to_none=True)
     out = m(x); loss = loss_fn(out, y); loss.backward(); return out, loss
@@ -34,3 +39,17 @@ if os.environ.get("SF_PROFILE"):
         step(); torch.cuda.synchronize()
     print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=22, max_name_column_width=60))
     print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=10, max_name_column_width=60))
+if os.environ.get("SF_GRAPH"):
+    from src.utils.graphed import GraphedStep
+    out, loss = step(); torch.cuda.synchronize()
+    eager = {k: p.grad.clone() for k, p in m.named_parameters()}; eager_loss = float(loss.detach())
+    torch.cuda.synchronize(); torch.cuda.set_stream(torch.cuda.default_stream())
+    gs = GraphedStep(m, loss_fn, [x], y)
+    o2, l2 = gs([x], y); torch.cuda.synchronize()
+    same = all(torch.equal(eager[k], p.grad) for k, p in m.named_parameters())
+    print("graph vs eager: loss", float(l2.detach()), eager_loss, "grads identical:", same, flush=True)
+    for _ in range(3): gs([x], y)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20): gs([x], y)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
+    print(f"graphed: {dt*1e3:.2f} ms/step = {B/dt:.1f} clips/s")

@@ -108,6 +108,14 @@ def main():
     ap.add_argument("--torch-optimizer", action="store_true", help="torch clip_grad_norm_ + fused AdamW instead of src.optim.ClipAdamW")
     args = ap.parse_args()
 
+    # The GPU box exposes every hardware thread of the host but grants one GPU's share of CPU time (cgroup quota: 16 CPUs).  A torch
+    # CPU op that fans out over all visible threads spends that quota within milliseconds and the whole process - including the
+    # thread that queues GPU work - is then throttled for the rest of the 100 ms scheduler period (measured: 88 ms stalls in
+    # tools/latency.py until OMP threads were limited).  Bound the intra-op pool before anything runs.
+    try:
+        torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    except Exception:
+        torch.set_num_threads(16)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

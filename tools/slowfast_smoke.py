@@ -3,6 +3,7 @@ finite outputs/gradients, and a rough clips/s (correctness-first path: one layou
     python tools/slowfast_smoke.py [B]"""
 import sys, os, time; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'disruption-prediciton-based-on-multimodal-deep-learning_amd'))
 import torch
+torch.set_num_threads(min(16, os.cpu_count() or 16))   # stay inside the box's CPU quota (see bench.py)
 from src.models.slowfast import SlowFast
 from src.loss import LDAMLoss
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4

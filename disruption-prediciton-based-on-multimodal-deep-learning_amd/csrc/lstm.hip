@@ -122,6 +122,131 @@ __global__ __launch_bounds__(256) void k_lstm_wgrad(const float* __restrict__ dp
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Register-resident recurrence (H = 64 or 128; MLSTM_FCN's and CnnLSTM's sizes).  The kernels above stream W_ih and W_hh from
+// memory at every time step, one uncoalesced row per thread: 73 us per step at H = 128, I = 256, all of it on the sequential
+// path (cfg5: 30 of 41 ms per training step).  Here the input projection x W_ih^T for ALL steps is one MFMA GEMM outside
+// (LinearRowsFunction, which also owns dx and dW_ih through its own backward), and the workgroup of 4H threads keeps W_hh in
+// registers for the whole sequence: thread j holds row j (forward: pre_j = xproj_j + b_j + <W_hh[j], h>), or, backward, column k of
+// one quarter of the rows (dh_k = sum_j W_hh[j][k] dpre_j as four partial sums added in a fixed order).  Per step only h / dpre
+// travel through LDS as broadcast ds_read_b128.
+template <int H>
+__global__ __launch_bounds__(4 * H) void k_lstm_rec_fwd(const float* __restrict__ xproj, const float* __restrict__ w_hh,
+                                                       const float* __restrict__ b_ih, const float* __restrict__ b_hh, int S, int B,
+                                                       int reverse, float* __restrict__ h_all, float* __restrict__ c_all,
+                                                       float* __restrict__ gates) {
+  __shared__ __attribute__((aligned(16))) float hprev[H];
+  __shared__ float cprev[H];
+  __shared__ float pre[4 * H];
+  const int b = blockIdx.x, j = threadIdx.x;
+  float w[H];
+#pragma unroll
+  for (int k = 0; k < H; k += 4) {
+    const float4 v = *(const float4*)(w_hh + (size_t)j * H + k);
+    w[k] = v.x; w[k + 1] = v.y; w[k + 2] = v.z; w[k + 3] = v.w;
+  }
+  const float bias = b_ih[j] + b_hh[j];
+  if (j < H) { hprev[j] = 0.f; cprev[j] = 0.f; }
+  __syncthreads();
+  for (int step = 0; step < S; ++step) {
+    const int ts = reverse ? S - 1 - step : step;
+    const size_t row = (size_t)ts * B + b;
+    float a = xproj[row * 4 * H + j] + bias;
+#pragma unroll
+    for (int k = 0; k < H; k += 4) {
+      const float4 hv = *(const float4*)(hprev + k);
+      a = fmaf(w[k], hv.x, a); a = fmaf(w[k + 1], hv.y, a); a = fmaf(w[k + 2], hv.z, a); a = fmaf(w[k + 3], hv.w, a);
+    }
+    pre[j] = a;
+    __syncthreads();
+    if (j < H) {
+      const float ig = sigm(pre[j]), fg = sigm(pre[H + j]), gg = tanhf(pre[2 * H + j]), og = sigm(pre[3 * H + j]);
+      const float c = fg * cprev[j] + ig * gg;
+      const float h = og * tanhf(c);
+      float* gt = gates + row * 4 * H;
+      gt[j] = ig; gt[H + j] = fg; gt[2 * H + j] = gg; gt[3 * H + j] = og;
+      c_all[row * H + j] = c; h_all[row * H + j] = h;
+      cprev[j] = c; hprev[j] = h;
+    }
+    __syncthreads();
+  }
+}
+template <int H>
+__global__ __launch_bounds__(4 * H) void k_lstm_rec_bwd(const float* __restrict__ dh_all, const float* __restrict__ w_hh,
+                                                       const float* __restrict__ c_all, const float* __restrict__ gates, int S, int B,
+                                                       int reverse, float* __restrict__ dpre) {
+  __shared__ float dh[H];
+  __shared__ float dc[H];
+  __shared__ __attribute__((aligned(16))) float dg[4 * H];
+  __shared__ float part[4][H];
+  const int b = blockIdx.x, t = threadIdx.x, p = t / H, k = t - p * H;
+  float w[H];                                            // w[jj] = W_hh[p H + jj][k]
+#pragma unroll
+  for (int jj = 0; jj < H; ++jj) w[jj] = w_hh[(size_t)(p * H + jj) * H + k];
+  if (t < H) { dh[t] = 0.f; dc[t] = 0.f; }
+  __syncthreads();
+  for (int step = S - 1; step >= 0; --step) {
+    const int ts = reverse ? S - 1 - step : step;
+    const int tprev = reverse ? ts + 1 : ts - 1;
+    const size_t row = (size_t)ts * B + b;
+    if (t < H) {
+      const float* gt = gates + row * 4 * H;
+      const float ig = gt[t], fg = gt[H + t], gg = gt[2 * H + t], og = gt[3 * H + t];
+      const float c = c_all[row * H + t];
+      const float cp = step > 0 ? c_all[((size_t)tprev * B + b) * H + t] : 0.f;
+      const float tc = tanhf(c);
+      const float dht = dh_all[row * H + t] + dh[t];
+      const float dct = dc[t] + dht * og * (1.f - tc * tc);
+      dg[t] = dct * gg * ig * (1.f - ig);
+      dg[H + t] = dct * cp * fg * (1.f - fg);
+      dg[2 * H + t] = dct * ig * (1.f - gg * gg);
+      dg[3 * H + t] = dht * tc * og * (1.f - og);
+      dc[t] = dct * fg;
+    }
+    __syncthreads();
+    dpre[row * 4 * H + t] = dg[t];
+    float a = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < H; jj += 4) {
+      const float4 d = *(const float4*)(dg + p * H + jj);
+      a = fmaf(w[jj], d.x, a); a = fmaf(w[jj + 1], d.y, a); a = fmaf(w[jj + 2], d.z, a); a = fmaf(w[jj + 3], d.w, a);
+    }
+    part[p][k] = a;
+    __syncthreads();
+    if (t < H) dh[t] = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+    __syncthreads();
+  }
+}
+extern "C" int md_lstm_rec_supported(int32_t H) { return (H == 64 || H == 128) ? 1 : 0; }
+// xproj [S][B][4H] = x W_ih^T (no bias); the biases are added here.
+extern "C" int md_lstm_rec_fwd(const float* xproj, const float* w_hh, const float* b_ih, const float* b_hh, int32_t S, int32_t B, int32_t H,
+                               int32_t reverse, float* h_all, float* c_all, float* gates, void* stream) {
+  if (!xproj || !w_hh || !b_ih || !b_hh || !h_all || !c_all || !gates) return MD_ERR_NULL;
+  if (S <= 0 || B <= 0) return MD_ERR_BAD_SHAPE;
+  if (!md_lstm_rec_supported(H)) return MD_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (H == 64) MD_KLAUNCH(k_lstm_rec_fwd<64>, dim3(B), dim3(256), 0, s, xproj, w_hh, b_ih, b_hh, S, B, reverse, h_all, c_all, gates);
+  else MD_KLAUNCH(k_lstm_rec_fwd<128>, dim3(B), dim3(512), 0, s, xproj, w_hh, b_ih, b_hh, S, B, reverse, h_all, c_all, gates);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+// dpre [S][B][4H] (= gradient of xproj), dw_hh [4H][H], db [4H]
+extern "C" int md_lstm_rec_bwd(const float* dh_all, const float* w_hh, const float* h_all, const float* c_all, const float* gates,
+                               int32_t S, int32_t B, int32_t H, int32_t reverse, float* dpre, float* dw_hh, float* db, void* stream) {
+  if (!dh_all || !w_hh || !h_all || !c_all || !gates || !dpre || !dw_hh || !db) return MD_ERR_NULL;
+  if (S <= 0 || B <= 0) return MD_ERR_BAD_SHAPE;
+  if (!md_lstm_rec_supported(H)) return MD_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (H == 64) MD_KLAUNCH(k_lstm_rec_bwd<64>, dim3(B), dim3(256), 0, s, dh_all, w_hh, c_all, gates, S, B, reverse, dpre);
+  else MD_KLAUNCH(k_lstm_rec_bwd<128>, dim3(B), dim3(512), 0, s, dh_all, w_hh, c_all, gates, S, B, reverse, dpre);
+  MD_CHECK_LAUNCH();
+  const int total = 4 * H * (H + 1);
+  MD_KLAUNCH(k_lstm_wgrad, dim3(md_cdiv(total, 256)), dim3(256), 0, s, (const float*)dpre, (const float*)nullptr, h_all, S, B, 0, H, reverse,
+             (float*)nullptr, dw_hh, db);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+
 extern "C" int md_lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                            int32_t S, int32_t B, int32_t I, int32_t H, int32_t reverse, float* h_all, float* c_all,
                            float* gates, void* stream) {

@@ -102,6 +102,9 @@ SIGNATURES = {
     "md_attention_fwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
     "md_attention_bwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
     "md_elu": (C.c_int, [_P, _P, _F, C.c_int64, _P, _P]),
+    "md_lstm_rec_supported": (C.c_int, [_I32]),
+    "md_lstm_rec_fwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P]),
+    "md_lstm_rec_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P]),
     "md_clip_preprocess": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, C.POINTER(C.c_float), _I32, _P, _P]),
     "md_outer_fwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P]),
     "md_outer_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _P, _P, _P]),

@@ -229,6 +229,47 @@ class LSTMDirectionFunction(torch.autograd.Function):
         return dx, dw_ih, dw_hh, db, db.clone(), None
 
 
+class LSTMRecurrentFunction(torch.autograd.Function):
+    """The recurrence of one LSTM direction on a precomputed input projection: xproj (S,B,4H) = x W_ih^T -> h (S,B,H), with W_hh
+    held in registers for the whole sequence (md_lstm_rec_*; H = 64 / 128)."""
+
+    @staticmethod
+    def forward(ctx, xproj, w_hh, b_ih, b_hh, reverse):
+        xproj = ops.f32(xproj).contiguous()
+        ops.require_cuda(xproj, w_hh, b_ih, b_hh)
+        S, B, H4 = xproj.shape
+        H = H4 // 4
+        h = torch.empty((S, B, H), device=xproj.device, dtype=torch.float32)
+        c = torch.empty_like(h)
+        gates = torch.empty_like(xproj)
+        N.check(N.lib().md_lstm_rec_fwd(ops._p(xproj), ops._p(w_hh.contiguous()), ops._p(b_ih.contiguous()), ops._p(b_hh.contiguous()), S, B,
+                                        H, int(bool(reverse)), ops._p(h), ops._p(c), ops._p(gates), ops._stream()), "md_lstm_rec_fwd")
+        ctx.save_for_backward(w_hh, h, c, gates)
+        ctx.reverse = int(bool(reverse))
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        w_hh, h, c, gates = ctx.saved_tensors
+        S, B, H = h.shape
+        dpre = torch.empty_like(gates)
+        dw_hh = torch.empty((4 * H, H), device=h.device); db = torch.empty(4 * H, device=h.device)
+        N.check(N.lib().md_lstm_rec_bwd(ops._p(ops.f32(dh).contiguous()), ops._p(w_hh.contiguous()), ops._p(h), ops._p(c), ops._p(gates), S, B, H,
+                                        ctx.reverse, ops._p(dpre), ops._p(dw_hh), ops._p(db), ops._stream()), "md_lstm_rec_bwd")
+        return dpre, dw_hh, db, db.clone(), None
+
+
+def lstm_direction(x, w_ih, w_hh, b_ih, b_hh, reverse):
+    """One direction of one layer: register-resident recurrence behind an MFMA input projection where the width allows,
+    else the general kernels."""
+    H = w_hh.shape[1]
+    if N.lib().md_lstm_rec_supported(int(H)):
+        S, B, I = x.shape
+        xproj = LinearRowsFunction.apply(x.reshape(S * B, I), w_ih).reshape(S, B, 4 * H)
+        return LSTMRecurrentFunction.apply(xproj, w_hh, b_ih, b_hh, reverse)
+    return LSTMDirectionFunction.apply(x, w_ih, w_hh, b_ih, b_hh, reverse)
+
+
 def lstm_forward(x, lstm: torch.nn.LSTM):
     """nn.LSTM(batch_first=False, zero initial state, no dropout, no projection) on the gfx950 kernels: returns the output
     sequence (S, B, num_directions*H) -- what the reference's encoders consume (CnnLSTM.py:96-97)."""
@@ -245,8 +286,8 @@ def lstm_forward(x, lstm: torch.nn.LSTM):
         dirs = []
         for rev in range(2 if lstm.bidirectional else 1):
             sfx = f"_l{layer}" + ("_reverse" if rev else "")
-            dirs.append(LSTMDirectionFunction.apply(out, getattr(lstm, "weight_ih" + sfx), getattr(lstm, "weight_hh" + sfx),
-                                                    getattr(lstm, "bias_ih" + sfx), getattr(lstm, "bias_hh" + sfx), rev))
+            dirs.append(lstm_direction(out, getattr(lstm, "weight_ih" + sfx), getattr(lstm, "weight_hh" + sfx),
+                                       getattr(lstm, "bias_ih" + sfx), getattr(lstm, "bias_hh" + sfx), rev))
         out = dirs[0] if len(dirs) == 1 else torch.cat(dirs, dim=2)
     return out
 

@@ -260,6 +260,14 @@ int md_outer_bwd(const float* a, const float* c, const float* dout, int32_t B, i
  * kept for the backward); reverse != 0 processes t = S-1 .. 0 (the "_reverse" direction).  The backward takes the gradient
  * with respect to every output h_t and returns dx, dW_ih [4H][I], dW_hh [4H][H] and db [4H] (the gradient of b_ih and of
  * b_hh); dpre_scratch: S*B*4H floats. */
+/* Register-resident form for H = 64 / 128 (md_lstm_rec_supported): the input projection xproj [S][B][4H] = x W_ih^T is computed by the
+ * caller as one GEMM (which then also owns dx and dW_ih); the recurrence keeps W_hh in registers for the whole sequence.  The
+ * backward returns dpre [S][B][4H] (the gradient of xproj), dW_hh and db (for b_ih and b_hh alike). */
+int md_lstm_rec_supported(int32_t H);
+int md_lstm_rec_fwd(const float* xproj, const float* w_hh, const float* b_ih, const float* b_hh, int32_t S, int32_t B, int32_t H,
+                    int32_t reverse, float* h_all, float* c_all, float* gates, void* stream);
+int md_lstm_rec_bwd(const float* dh_all, const float* w_hh, const float* h_all, const float* c_all, const float* gates, int32_t S,
+                    int32_t B, int32_t H, int32_t reverse, float* dpre, float* dw_hh, float* db, void* stream);
 int md_lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, int32_t S,
                 int32_t B, int32_t I, int32_t H, int32_t reverse, float* h_all, float* c_all, float* gates, void* stream);
 int md_lstm_bwd(const float* dh_all, const float* x, const float* w_ih, const float* w_hh, const float* h_all,

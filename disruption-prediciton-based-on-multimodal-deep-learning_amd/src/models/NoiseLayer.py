@@ -35,10 +35,38 @@ class NoiseLayer(nn.Module):
         if not self.training:
             return x
         ops.require_cuda(x)
-        return _AddNoise.apply(ops.f32(x), self._draw(x), self.mean, self.std)
+        noise = self._draw_static(x) if self.__dict__.get("_graph_mode") else self._draw(x)
+        return _AddNoise.apply(ops.f32(x), noise, self.mean, self.std)
+
+    # -- whole-step HIP graphs (src/utils/graphed.py): the upload must read the SAME pinned buffer on every replay, and the host
+    #    refills it from the CPU generator before each replay (refresh_static), so the noise stream stays the reference's
+    def _draw_static(self, x):
+        st = self.__dict__.get("_static")
+        capturing = torch.cuda.is_current_stream_capturing()
+        if st is None or st[0].shape != x.shape:
+            if capturing:
+                raise RuntimeError("NoiseLayer: graph mode needs one eager forward (warm-up) before the capture")
+            st = (torch.empty(x.shape, dtype=torch.float32).pin_memory(), torch.empty(x.shape, dtype=torch.float32, device=x.device),
+                  torch.cuda.Event())
+            self.__dict__["_static"] = st
+        host, dev, done = st
+        if not capturing:
+            done.synchronize()
+            torch.randn(x.size(), out=host)
+        dev.copy_(host, non_blocking=True)
+        if not capturing:
+            done.record(torch.cuda.current_stream(x.device))
+        return dev
+
+    def refresh_static(self):
+        """Draw the next noise tensor into the pinned buffer a captured step uploads from (call before each replay, after the
+        previous replay has finished)."""
+        st = self.__dict__.get("_static")
+        if st is not None and self.training:
+            torch.randn(st[0].size(), out=st[0])
 
     def __getstate__(self):                                      # the staging ring (pinned memory, events) is per process
-        return {k: v for k, v in self.__dict__.items() if k != "_ring"}
+        return {k: v for k, v in self.__dict__.items() if k not in ("_ring", "_static", "_graph_mode")}
 
     def __deepcopy__(self, memo):
         return NoiseLayer(self.mean, self.std).train(self.training)

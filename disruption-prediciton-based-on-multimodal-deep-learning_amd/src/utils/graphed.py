@@ -3,8 +3,8 @@ is several hundred small launches issued from Python, and the host, not the GPU,
 kernels in a 13.7 ms step).  ``GraphedStep`` records forward + loss + backward once into a HIP graph (``torch.cuda.CUDAGraph``:
 every kernel of this library is launched on torch's current stream, so stream capture sees them) and replays it per batch; the
 optimizer step stays outside.  Requirements, as for any captured step: fixed input shapes, no host synchronisation inside
-the step (modules that draw from the CPU generator - the NoiseLayer of the 0D encoders - are refused), random masks only from
-torch's device generator (capture-aware).  Gradients live in static tensors that the graph overwrites on every replay.
+the step, random masks only from torch's device generator (capture-aware); the NoiseLayer of the 0D encoders, which draws from
+the CPU generator as the reference does, is switched to a pinned staging buffer that is refilled before every replay.  Gradients live in static tensors that the graph overwrites on every replay.
 Observed on this stack (ROCm 7.2, torch 2.10): if the model has already run forward + backward on the LEGACY DEFAULT stream in
 the process, ending the capture crashes inside the runtime; steps run on any other stream beforehand are fine.  Construct the
 GraphedStep first, or keep eager work under ``torch.cuda.stream(side)``.
@@ -17,10 +17,13 @@ import torch
 class GraphedStep:
     def __init__(self, model: torch.nn.Module, loss_fn: Callable, example_inputs: Sequence[torch.Tensor], example_target: torch.Tensor,
                  warmup: int = 3):
-        for mod in model.modules():
-            if type(mod).__name__ == "NoiseLayer" and mod.training and mod.std != 0:
-                raise RuntimeError("GraphedStep: NoiseLayer draws from the CPU generator every step and cannot be captured")
+        # NoiseLayers draw from the CPU generator: switched to one pinned staging buffer each, which the captured upload reads on
+        # every replay and __call__ refills beforehand
+        self.noise_layers = [mod for mod in model.modules() if type(mod).__name__ == "NoiseLayer"]
+        for mod in self.noise_layers:
+            mod.__dict__["_graph_mode"] = True
         self.model, self.loss_fn = model, loss_fn
+        self._done = torch.cuda.Event()
         self.inputs = [t.detach().clone() for t in example_inputs]
         self.target = example_target.detach().clone()
         side = torch.cuda.Stream()
@@ -45,8 +48,14 @@ class GraphedStep:
     def __call__(self, inputs: Sequence[torch.Tensor], target: torch.Tensor):
         """Copies the batch into the static buffers, replays the step; returns (outputs, loss) - static tensors, valid until
         the next call.  Parameter ``.grad`` tensors hold this batch's gradients afterwards."""
+        if self.noise_layers:
+            self._done.synchronize()                       # the previous replay no longer reads the staging buffers
+            for mod in self.noise_layers:
+                mod.refresh_static()
         for dst, src in zip(self.inputs, inputs):
             dst.copy_(src, non_blocking=True)
         self.target.copy_(target, non_blocking=True)
         self.graph.replay()
+        if self.noise_layers:
+            self._done.record()
         return self.outputs, self.loss

@@ -32,6 +32,27 @@ xv = torch.randn(B, 3, 32, 224, 224, device="cuda") * 50; xt = torch.randn(B, 21
 y = (torch.arange(B) % 2).cuda()
 
 
+if os.environ.get("CFG5_GRAPH"):
+    # whole forward + loss + backward as one HIP graph (fresh process: nothing eager on the default stream before the capture)
+    from src.utils.graphed import GraphedStep
+    gs = GraphedStep(m, lambda a, b, c, t: gb(a, b, c, t), [xv, xt], y)
+    def gstep():
+        _, loss = gs([xv, xt], y)
+        opt.step()
+        return loss
+    for _ in range(3):
+        gstep()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = gstep()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+    assert bool(torch.isfinite(loss))
+    print(json.dumps({"metric": "clips/sec (full step) SlowFast + MLSTM_FCN, GradientBlending over LDAM + DRW weights; forward+loss+backward as one HIP graph",
+                      "value": round(B / dt, 1), "unit": "clips/s", "n_gpus": 1, "steps": steps, "warmup": 3, "ms_per_step": round(dt * 1e3, 3),
+                      "higher_is_better": True, "data": "synthetic", "loss": float(loss.detach())}))
+    sys.exit(0)
+
+
 def step():
     opt.zero_grad(set_to_none=True)
     o = m(xv, xt)

@@ -18,7 +18,7 @@ import torch.nn as nn
 from .. import _native as N
 from .. import ops
 from .NoiseLayer import NoiseLayer
-from ._unit import (ConvBnLeakyFunction, ConvFunction, HeadFunction, lstm_forward, _AbsorbedBias, _ChannelBias,
+from ._unit import (ConvBnLeakyFunction, ConvFunction, HeadFunction, head_apply, lstm_forward, _AbsorbedBias, _ChannelBias,
                     _SeqSum)
 
 
@@ -99,11 +99,7 @@ class CnnLSTM(nn.Module):
     def forward(self, x: torch.Tensor):
         hidden = self._hidden(x)
         lin0, bn, lin1 = self.classifier[0], self.classifier[1], self.classifier[3]
-        out = HeadFunction.apply(hidden, lin0.weight, lin0.bias, bn.weight, bn.bias, lin1.weight, lin1.bias, bn.running_mean,
-                                 bn.running_var, 0.0, float(bn.eps), float(bn.momentum), bool(self.training))
-        if self.training:
-            bn.num_batches_tracked += 1
-        return out
+        return head_apply(hidden, lin0, bn, lin1, 0.0, bool(self.training))
 
     def summary(self, device: str = 'cpu', show_input: bool = True, show_hierarchical: bool = False, print_summary: bool = False,
                 show_parent_layers: bool = False):

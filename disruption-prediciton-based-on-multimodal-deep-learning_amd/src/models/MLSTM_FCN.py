@@ -15,7 +15,7 @@ import torch.nn as nn
 from .. import _native as N
 from .. import ops
 from .NoiseLayer import NoiseLayer
-from ._unit import GlobalAvgPoolFunction, HeadFunction, _SeqSum, conv1d_bn_leaky, linear, lstm_forward
+from ._unit import GlobalAvgPoolFunction, HeadFunction, head_apply, _SeqSum, conv1d_bn_leaky, linear, lstm_forward
 
 
 class _SEScaleFunction(torch.autograd.Function):
@@ -141,12 +141,7 @@ class MLSTM_FCN(nn.Module):
     def _head(self, f: torch.Tensor):
         lin0, bn, act, lin1 = self.classifier[0], self.classifier[1], self.classifier[2], self.classifier[3]
         slope = float(act.negative_slope)
-        out = HeadFunction.apply(f, lin0.weight, lin0.bias, bn.weight, bn.bias, lin1.weight, lin1.bias, bn.running_mean,
-                                 bn.running_var, -slope if slope != 0.0 else 0.0, float(bn.eps), float(bn.momentum),
-                                 bool(self.training))                       # alpha < 0 selects LeakyReLU(-alpha) in md_head_*
-        if self.training:
-            bn.num_batches_tracked += 1
-        return out
+        return head_apply(f, lin0, bn, lin1, -slope if slope != 0.0 else 0.0, bool(self.training))   # alpha < 0: LeakyReLU(-alpha)
 
     def encode(self, x: torch.Tensor):
         with torch.no_grad():

@@ -194,13 +194,9 @@ class _Head(nn.Sequential):
     """Linear -> BatchNorm1d -> ELU -> Linear (reference R2Plus1D.py:243-248) as ONE fused HIP kernel pair."""
 
     def forward(self, f: torch.Tensor):
-        from ._unit import HeadFunction
+        from ._unit import head_apply
         lin0, bn, elu, lin1 = self[0], self[1], self[2], self[3]
-        out = HeadFunction.apply(f, lin0.weight, lin0.bias, bn.weight, bn.bias, lin1.weight, lin1.bias, bn.running_mean,
-                                 bn.running_var, float(elu.alpha), float(bn.eps), float(bn.momentum), self.training)
-        if self.training:
-            bn.num_batches_tracked += 1
-        return out
+        return head_apply(f, lin0, bn, lin1, float(elu.alpha), self.training)
 
 
 class R2Plus1DClassifier(nn.Module):

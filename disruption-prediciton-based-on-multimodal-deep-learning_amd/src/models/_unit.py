@@ -610,3 +610,22 @@ def dropout(x, p: float, training: bool):
         return x
     keep = 1.0 - p
     return _MaskScale.apply(x, torch.empty_like(x).bernoulli_(keep), 1.0 / keep)
+
+
+def head_apply(f, lin0: torch.nn.Linear, bn: torch.nn.BatchNorm1d, lin1: torch.nn.Linear, alpha: float, training: bool):
+    """Classifier head Linear -> BatchNorm1d -> activation -> Linear; alpha >= 0: ELU(alpha) (0 = ReLU), alpha < 0:
+    LeakyReLU(-alpha).  The fused single-workgroup kernels (md_head_*) keep two (B, hidden) tiles in LDS; where those do not
+    fit (MLSTM_FCN's 512 -> 256 head at batch 32, BASELINE configs[0]) the head is composed from the Linear+BatchNorm1d unit,
+    md_elu and the MFMA Linear instead."""
+    B, Hd = f.shape[0], lin0.out_features
+    if 2 * B * Hd * 4 <= 60000:
+        out = HeadFunction.apply(f, lin0.weight, lin0.bias, bn.weight, bn.bias, lin1.weight, lin1.bias, bn.running_mean, bn.running_var,
+                                 float(alpha), float(bn.eps), float(bn.momentum), bool(training))
+        if training:
+            bn.num_batches_tracked += 1
+        return out
+    if alpha < 0:
+        h = linear_bn_leaky(f, lin0, bn, -float(alpha), bool(training))
+    else:
+        h = EluFunction.apply(linear_bn_leaky(f, lin0, bn, 1.0, bool(training)), float(alpha))
+    return linear_wb(h, lin1.weight, lin1.bias)

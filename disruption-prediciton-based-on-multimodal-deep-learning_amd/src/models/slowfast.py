@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from .resnet import *          # noqa: F401,F403  (as the reference does, slowfast.py:5)
 from .resnet import Bottleneck3D, ResNet3D
-from ._unit import GlobalAvgPoolFunction, HeadFunction, conv_plain
+from ._unit import GlobalAvgPoolFunction, conv_plain, head_apply
 
 
 _STAGES = ("layer1", "layer2", "layer3", "layer4")
@@ -114,11 +114,7 @@ class SlowFastClassifier(nn.Module):
 
     def forward(self, x: torch.Tensor):
         lin0, bn, elu, lin1 = self.classifier[0], self.classifier[1], self.classifier[2], self.classifier[3]
-        out = HeadFunction.apply(x, lin0.weight, lin0.bias, bn.weight, bn.bias, lin1.weight, lin1.bias, bn.running_mean,
-                                 bn.running_var, float(elu.alpha), float(bn.eps), float(bn.momentum), bool(self.training))
-        if self.training:
-            bn.num_batches_tracked += 1
-        return out
+        return head_apply(x, lin0, bn, lin1, float(elu.alpha), bool(self.training))
 
 
 class SlowFast(nn.Module):

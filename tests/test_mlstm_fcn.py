@@ -86,3 +86,38 @@ def test_lstm_interlayer_dropout():
     c = lstm_forward(x, lstm); d = lstm_forward(x, lstm)
     assert not torch.equal(c, d)                                    # training: a fresh mask per call
     assert 0.5 < float(c.abs().mean() / a.abs().mean()) < 2.0       # inverted dropout keeps the scale
+
+
+@pytest.mark.gpu
+def test_cfg1_batch32_head_is_composed_from_units():
+    """BASELINE configs[0] (script defaults, batch 32): the 512 -> 256 head at B = 32 does not fit the fused head kernels' LDS tiles
+    and is composed from the Linear+BatchNorm1d unit and the MFMA Linear (models/_unit.py::head_apply); logits, input gradient
+    and parameter gradients against the oracle restatement (pinned by the reference fixture above) run on the CPU."""
+    from oracle import mlstm_fcn as om
+    from src.models.MLSTM_FCN import MLSTM_FCN
+    torch.manual_seed(21)
+    m = MLSTM_FCN(n_features=14, fcn_dim=128, kernel_size=3, stride=1, seq_len=21, lstm_dim=128, lstm_n_layers=4, lstm_bidirectional=True,
+                  lstm_dropout=0.0, reduction=16, alpha=0.01, n_classes=2)
+    m.noise.std = 0.0
+    assert 2 * 32 * m.classifier[0].out_features * 4 > 60000
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k}
+    ref_sd = dict(sd); ref_sd.update(leaves)
+    x = torch.randn(32, 21, 14); dout = torch.randn(32, 2)
+    xr = x.clone().requires_grad_(True)
+    ref = om.mlstm_fcn_forward(xr, ref_sd, kernel_size=3, stride=1, lstm_n_layers=4, bidirectional=True, alpha=0.01, training=True)
+    ref.backward(dout)
+    m.cuda().train()
+    xg = x.cuda().requires_grad_(True)
+    out = m(xg)
+    out.backward(dout.cuda())
+    rel = lambda a, b: float((a.double().cpu() - b.double()).norm() / max(1e-12, float(b.double().norm())))
+    assert float((out.detach().cpu() - ref.detach()).abs().max()) <= 1e-3 * max(1.0, float(ref.abs().max()))
+    assert rel(xg.grad, xr.grad) < 3e-3
+    gmax = max(float(v.grad.abs().max()) for v in leaves.values() if v.grad is not None)
+    for k, p in m.named_parameters():
+        r = leaves[k].grad
+        if r is None or float(r.abs().max()) < 1e-4 * gmax:
+            assert p.grad is None or float(p.grad.abs().max()) < 1e-3 * gmax, k
+            continue
+        assert rel(p.grad, r) < 3e-3, (k, rel(p.grad, r))

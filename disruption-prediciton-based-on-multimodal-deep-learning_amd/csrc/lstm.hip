@@ -233,13 +233,14 @@ extern "C" int md_lstm_rec_fwd(const float* xproj, const float* w_hh, const floa
 // dpre [S][B][4H] (= gradient of xproj), dw_hh [4H][H], db [4H]
 extern "C" int md_lstm_rec_bwd(const float* dh_all, const float* w_hh, const float* h_all, const float* c_all, const float* gates,
                                int32_t S, int32_t B, int32_t H, int32_t reverse, float* dpre, float* dw_hh, float* db, void* stream) {
-  if (!dh_all || !w_hh || !h_all || !c_all || !gates || !dpre || !dw_hh || !db) return MD_ERR_NULL;
+  if (!dh_all || !w_hh || !h_all || !c_all || !gates || !dpre || (!dw_hh != !db)) return MD_ERR_NULL;
   if (S <= 0 || B <= 0) return MD_ERR_BAD_SHAPE;
   if (!md_lstm_rec_supported(H)) return MD_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   if (H == 64) MD_KLAUNCH(k_lstm_rec_bwd<64>, dim3(B), dim3(256), 0, s, dh_all, w_hh, c_all, gates, S, B, reverse, dpre);
   else MD_KLAUNCH(k_lstm_rec_bwd<128>, dim3(B), dim3(512), 0, s, dh_all, w_hh, c_all, gates, S, B, reverse, dpre);
   MD_CHECK_LAUNCH();
+  if (!dw_hh) return MD_OK;          // the caller reduces dpre itself (many rows: MFMA weight gradient + column sums)
   const int total = 4 * H * (H + 1);
   MD_KLAUNCH(k_lstm_wgrad, dim3(md_cdiv(total, 256)), dim3(256), 0, s, (const float*)dpre, (const float*)nullptr, h_all, S, B, 0, H, reverse,
              (float*)nullptr, dw_hh, db);

@@ -253,9 +253,23 @@ class LSTMRecurrentFunction(torch.autograd.Function):
         w_hh, h, c, gates = ctx.saved_tensors
         S, B, H = h.shape
         dpre = torch.empty_like(gates)
-        dw_hh = torch.empty((4 * H, H), device=h.device); db = torch.empty(4 * H, device=h.device)
+        rows = S * B
+        # many (t, b) rows (the scripts' batch 256: 5376): dW_hh = dpre^T h_prev is a weight-gradient GEMM for the matrix cores and
+        # db a column sum; the one-thread-per-weight kernel took 5.3 ms per direction there (42 of CnnLSTM's 47 ms step)
+        gemm = rows >= 512 and not N.lib().md_get_exact_fp32()
+        dw_hh = None if gemm else torch.empty((4 * H, H), device=h.device)
+        db = torch.empty(4 * H, device=h.device)
         N.check(N.lib().md_lstm_rec_bwd(ops._p(ops.f32(dh).contiguous()), ops._p(w_hh.contiguous()), ops._p(h), ops._p(c), ops._p(gates), S, B, H,
-                                        ctx.reverse, ops._p(dpre), ops._p(dw_hh), ops._p(db), ops._stream()), "md_lstm_rec_bwd")
+                                        ctx.reverse, ops._p(dpre), ops._p(dw_hh), None if gemm else ops._p(db), ops._stream()),
+                "md_lstm_rec_bwd")
+        if gemm:
+            zero = h.new_zeros(1, B, H)
+            hprev = torch.cat((h[1:], zero)) if ctx.reverse else torch.cat((zero, h[:-1]))       # h of the step processed before
+            d = ops.make_desc(1, 1, 1, rows, H, 4 * H, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+            dw_hh = ops.conv_wgrad(d, ops.view(hprev.view(rows, H)), dpre.view(rows, 4 * H)).view(4 * H, H)
+            ns = N.lib().md_channel_bias_bwd_scratch_floats(rows, 4 * H, 1)
+            scratch = torch.empty(ns, device=h.device) if ns else None
+            N.check(N.lib().md_channel_bias_bwd(ops._p(dpre), rows, 4 * H, 1, ops._p(db), ops._p(scratch), ops._stream()), "md_channel_bias_bwd")
         return dpre, dw_hh, db, db.clone(), None
 
 

@@ -262,7 +262,8 @@ int md_outer_bwd(const float* a, const float* c, const float* dout, int32_t B, i
  * b_hh); dpre_scratch: S*B*4H floats. */
 /* Register-resident form for H = 64 / 128 (md_lstm_rec_supported): the input projection xproj [S][B][4H] = x W_ih^T is computed by the
  * caller as one GEMM (which then also owns dx and dW_ih); the recurrence keeps W_hh in registers for the whole sequence.  The
- * backward returns dpre [S][B][4H] (the gradient of xproj), dW_hh and db (for b_ih and b_hh alike). */
+ * backward returns dpre [S][B][4H] (the gradient of xproj), dW_hh and db (for b_ih and b_hh alike); with dw_hh = db = NULL only
+ * dpre (the caller then forms dW_hh = dpre^T h_prev and db = column sums of dpre with the GEMM / reduction kernels). */
 int md_lstm_rec_supported(int32_t H);
 int md_lstm_rec_fwd(const float* xproj, const float* w_hh, const float* b_ih, const float* b_hh, int32_t S, int32_t B, int32_t H,
                     int32_t reverse, float* h_all, float* c_all, float* gates, void* stream);

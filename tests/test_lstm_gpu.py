@@ -12,7 +12,7 @@ if torch.cuda.is_available():
 
 
 @pytest.mark.parametrize("S,B,I,H,layers,bidir", [(32, 8, 21, 64, 1, True), (21, 5, 14, 128, 4, True), (7, 3, 5, 9, 2, False),
-                                                   (1, 2, 3, 4, 1, True)])
+                                                   (1, 2, 3, 4, 1, True), (21, 64, 12, 128, 2, True)])
 def test_lstm_matches_torch(S, B, I, H, layers, bidir):
     torch.manual_seed(S * 7 + H)
     ref = torch.nn.LSTM(I, H, num_layers=layers, bidirectional=bidir, batch_first=False)
@@ -30,5 +30,7 @@ def test_lstm_matches_torch(S, B, I, H, layers, bidir):
     rel = lambda a, b: float((a.double() - b.double()).abs().max() / max(1e-12, float(b.double().abs().max())))
     assert rel(og.detach().cpu(), out.detach()) < 2e-6
     assert rel(xg.grad.cpu(), xr.grad) < 2e-5
+    # >= 512 (t, b) rows: dW_hh comes from the split-precision (3 x bf16) weight-gradient GEMM, fp32-level but not fp32-exact
+    ptol = 1e-4 if S * B >= 512 else 2e-5
     for (k, p), (_, q) in zip(ref.named_parameters(), mine.named_parameters()):
-        assert rel(q.grad.cpu(), p.grad) < 2e-5, k
+        assert rel(q.grad.cpu(), p.grad) < ptol, k

@@ -96,61 +96,65 @@ __global__ __launch_bounds__(256) void k_row_reduce(const float* __restrict__ a,
   if (threadIdx.x == 0) out[row] = MODE == 0 ? t / (float)thw : t;
 }
 
-// gate forward: one workgroup.  hidden[N][Wd] (post-ReLU) is kept for the backward.
+// gate forward: one workgroup per sample.  hidden[N][Wd] (post-ReLU) is kept for the backward.
 __global__ __launch_bounds__(256) void k_se_gate_fwd(const float* __restrict__ pool, const float* __restrict__ w1,
                                                      const float* __restrict__ b1, const float* __restrict__ w2,
                                                      const float* __restrict__ b2, int N, int Cc, int Wd,
                                                      float* __restrict__ hidden, float* __restrict__ gate) {
-  for (int e = threadIdx.x; e < N * Wd; e += 256) {
-    const int n = e / Wd, j = e - n * Wd;
+  const int n = blockIdx.x;
+  for (int j = threadIdx.x; j < Wd; j += 256) {
     float acc = b1[j];
     for (int c = 0; c < Cc; ++c) acc = fmaf(w1[j * Cc + c], pool[n * Cc + c], acc);
-    hidden[e] = acc > 0.f ? acc : 0.f;
+    hidden[n * Wd + j] = acc > 0.f ? acc : 0.f;
   }
-  __syncthreads();      // (single workgroup: the hidden values were written by this workgroup's threads)
+  __syncthreads();      // (the hidden values of this sample were written by this workgroup's threads)
   __threadfence_block();
-  for (int e = threadIdx.x; e < N * Cc; e += 256) {
-    const int n = e / Cc, c = e - n * Cc;
+  for (int c = threadIdx.x; c < Cc; c += 256) {
     float acc = b2[c];
     for (int j = 0; j < Wd; ++j) acc = fmaf(w2[c * Wd + j], hidden[n * Wd + j], acc);
-    gate[e] = sigmoidf_(acc);
+    gate[n * Cc + c] = sigmoidf_(acc);
   }
 }
 
-// gate backward: one workgroup.  dgate[N][C] -> dpool[N][C], dw1[Wd][C], db1[Wd], dw2[C][Wd], db2[C]; scratch dz2[N][C], dh[N][Wd].
-__global__ __launch_bounds__(256) void k_se_gate_bwd(const float* __restrict__ dgate, const float* __restrict__ gate,
-                                                     const float* __restrict__ hidden, const float* __restrict__ pool,
-                                                     const float* __restrict__ w1, const float* __restrict__ w2, int N,
-                                                     int Cc, int Wd, float* __restrict__ dz2, float* __restrict__ dh,
-                                                     float* __restrict__ dpool, float* __restrict__ dw1,
-                                                     float* __restrict__ db1, float* __restrict__ dw2,
-                                                     float* __restrict__ db2) {
-  const int t = threadIdx.x;
-  for (int e = t; e < N * Cc; e += 256) { const float s = gate[e]; dz2[e] = dgate[e] * s * (1.f - s); }
+// gate backward, per sample (one workgroup each): dgate[n][C] -> dz2[n][C], dh[n][Wd], dpool[n][C]
+__global__ __launch_bounds__(256) void k_se_gate_bwd_n(const float* __restrict__ dgate, const float* __restrict__ gate,
+                                                       const float* __restrict__ hidden, const float* __restrict__ w1,
+                                                       const float* __restrict__ w2, int Cc, int Wd, float* __restrict__ dz2,
+                                                       float* __restrict__ dh, float* __restrict__ dpool) {
+  const int n = blockIdx.x, t = threadIdx.x;
+  for (int c = t; c < Cc; c += 256) { const float s = gate[n * Cc + c]; dz2[n * Cc + c] = dgate[n * Cc + c] * s * (1.f - s); }
   __syncthreads(); __threadfence_block();
-  for (int e = t; e < Cc * Wd; e += 256) {
+  for (int j = t; j < Wd; j += 256) {
+    float acc = 0.f; for (int c = 0; c < Cc; ++c) acc = fmaf(dz2[n * Cc + c], w2[c * Wd + j], acc);
+    dh[n * Wd + j] = hidden[n * Wd + j] > 0.f ? acc : 0.f;
+  }
+  __syncthreads(); __threadfence_block();
+  for (int c = t; c < Cc; c += 256) {
+    float acc = 0.f; for (int j = 0; j < Wd; ++j) acc = fmaf(dh[n * Wd + j], w1[j * Cc + c], acc);
+    dpool[n * Cc + c] = acc;
+  }
+}
+// gate backward, parameters: one thread per element of dw2[C][Wd] | db2[C] | dw1[Wd][C] | db1[Wd], samples in order
+__global__ __launch_bounds__(256) void k_se_gate_bwd_w(const float* __restrict__ dz2, const float* __restrict__ dh,
+                                                       const float* __restrict__ hidden, const float* __restrict__ pool, int N, int Cc,
+                                                       int Wd, float* __restrict__ dw1, float* __restrict__ db1,
+                                                       float* __restrict__ dw2, float* __restrict__ db2) {
+  int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < Cc * Wd) {
     const int c = e / Wd, j = e - c * Wd;
     float acc = 0.f; for (int n = 0; n < N; ++n) acc = fmaf(dz2[n * Cc + c], hidden[n * Wd + j], acc);
-    dw2[e] = acc;
+    dw2[e] = acc; return;
   }
-  for (int c = t; c < Cc; c += 256) { float acc = 0.f; for (int n = 0; n < N; ++n) acc += dz2[n * Cc + c]; db2[c] = acc; }
-  for (int e = t; e < N * Wd; e += 256) {
-    const int n = e / Wd, j = e - n * Wd;
-    float acc = 0.f; for (int c = 0; c < Cc; ++c) acc = fmaf(dz2[n * Cc + c], w2[c * Wd + j], acc);
-    dh[e] = hidden[e] > 0.f ? acc : 0.f;
-  }
-  __syncthreads(); __threadfence_block();
-  for (int e = t; e < Wd * Cc; e += 256) {
+  e -= Cc * Wd;
+  if (e < Cc) { float acc = 0.f; for (int n = 0; n < N; ++n) acc += dz2[n * Cc + e]; db2[e] = acc; return; }
+  e -= Cc;
+  if (e < Wd * Cc) {
     const int j = e / Cc, c = e - j * Cc;
     float acc = 0.f; for (int n = 0; n < N; ++n) acc = fmaf(dh[n * Wd + j], pool[n * Cc + c], acc);
-    dw1[e] = acc;
+    dw1[e] = acc; return;
   }
-  for (int j = t; j < Wd; j += 256) { float acc = 0.f; for (int n = 0; n < N; ++n) acc += dh[n * Wd + j]; db1[j] = acc; }
-  for (int e = t; e < N * Cc; e += 256) {
-    const int n = e / Cc, c = e - n * Cc;
-    float acc = 0.f; for (int j = 0; j < Wd; ++j) acc = fmaf(dh[n * Wd + j], w1[j * Cc + c], acc);
-    dpool[e] = acc;
-  }
+  e -= Wd * Cc;
+  if (e < Wd) { float acc = 0.f; for (int n = 0; n < N; ++n) acc += dh[n * Wd + e]; db1[e] = acc; }
 }
 
 // MODE 0: out = swish(a*g);  MODE 1: da = dout*swish'(a*g)*g + dpool/thw;  MODE 2: out = relu(a+b);  MODE 3: dx = dout*(out>0)
@@ -184,7 +188,7 @@ extern "C" int md_se_swish_fwd(const float* a, int32_t N, int32_t Cc, int64_t th
   const int64_t n = (int64_t)N * Cc * thw;
   MD_KLAUNCH(k_row_reduce<0>, dim3(N * Cc), dim3(256), 0, s, a, (const float*)nullptr, (const float*)nullptr, thw, pool);
   MD_CHECK_LAUNCH();
-  MD_KLAUNCH(k_se_gate_fwd, dim3(1), dim3(256), 0, s, (const float*)pool, w1, b1, w2, b2, N, Cc, Wd, hidden, gate);
+  MD_KLAUNCH(k_se_gate_fwd, dim3(N), dim3(256), 0, s, (const float*)pool, w1, b1, w2, b2, N, Cc, Wd, hidden, gate);
   MD_CHECK_LAUNCH();
   MD_KLAUNCH(k_row_elem<0>, dim3(elem_blocks(n)), dim3(256), 0, s, a, (const float*)nullptr, (const float*)gate,
              (const float*)nullptr, thw, n, out);
@@ -204,8 +208,10 @@ extern "C" int md_se_swish_bwd(const float* a, const float* dout, int32_t N, int
   float* dgate = scratch; float* dz2 = scratch + (size_t)N * Cc; float* dpool = dz2 + (size_t)N * Cc; float* dh = dpool + (size_t)N * Cc;
   MD_KLAUNCH(k_row_reduce<1>, dim3(N * Cc), dim3(256), 0, s, a, gate, dout, thw, dgate);
   MD_CHECK_LAUNCH();
-  MD_KLAUNCH(k_se_gate_bwd, dim3(1), dim3(256), 0, s, (const float*)dgate, gate, hidden, pool, w1, w2, N, Cc, Wd, dz2, dh,
-             dpool, dw1, db1, dw2, db2);
+  MD_KLAUNCH(k_se_gate_bwd_n, dim3(N), dim3(256), 0, s, (const float*)dgate, gate, hidden, w1, w2, Cc, Wd, dz2, dh, dpool);
+  MD_CHECK_LAUNCH();
+  MD_KLAUNCH(k_se_gate_bwd_w, dim3(md_cdiv(2 * Cc * Wd + Cc + Wd, 256)), dim3(256), 0, s, (const float*)dz2, (const float*)dh, hidden, pool,
+             N, Cc, Wd, dw1, db1, dw2, db2);
   MD_CHECK_LAUNCH();
   MD_KLAUNCH(k_row_elem<1>, dim3(elem_blocks(n)), dim3(256), 0, s, a, dout, gate, (const float*)dpool, thw, n, da);
   MD_CHECK_LAUNCH();
@@ -223,7 +229,7 @@ extern "C" int md_se_scale_fwd(const float* a, int32_t N, int32_t Cc, int64_t th
   const int64_t n = (int64_t)N * Cc * thw;
   MD_KLAUNCH(k_row_reduce<0>, dim3(N * Cc), dim3(256), 0, s, a, (const float*)nullptr, (const float*)nullptr, thw, pool);
   MD_CHECK_LAUNCH();
-  MD_KLAUNCH(k_se_gate_fwd, dim3(1), dim3(256), 0, s, (const float*)pool, w1, b1, w2, b2, N, Cc, Wd, hidden, gate);
+  MD_KLAUNCH(k_se_gate_fwd, dim3(N), dim3(256), 0, s, (const float*)pool, w1, b1, w2, b2, N, Cc, Wd, hidden, gate);
   MD_CHECK_LAUNCH();
   MD_KLAUNCH(k_row_elem<4>, dim3(elem_blocks(n)), dim3(256), 0, s, a, (const float*)nullptr, (const float*)gate,
              (const float*)nullptr, thw, n, out);
@@ -241,8 +247,10 @@ extern "C" int md_se_scale_bwd(const float* a, const float* dout, int32_t N, int
   float* dgate = scratch; float* dz2 = scratch + (size_t)N * Cc; float* dpool = dz2 + (size_t)N * Cc; float* dh = dpool + (size_t)N * Cc;
   MD_KLAUNCH(k_row_reduce<2>, dim3(N * Cc), dim3(256), 0, s, a, gate, dout, thw, dgate);
   MD_CHECK_LAUNCH();
-  MD_KLAUNCH(k_se_gate_bwd, dim3(1), dim3(256), 0, s, (const float*)dgate, gate, hidden, pool, w1, w2, N, Cc, Wd, dz2, dh,
-             dpool, dw1, db1, dw2, db2);
+  MD_KLAUNCH(k_se_gate_bwd_n, dim3(N), dim3(256), 0, s, (const float*)dgate, gate, hidden, w1, w2, Cc, Wd, dz2, dh, dpool);
+  MD_CHECK_LAUNCH();
+  MD_KLAUNCH(k_se_gate_bwd_w, dim3(md_cdiv(2 * Cc * Wd + Cc + Wd, 256)), dim3(256), 0, s, (const float*)dz2, (const float*)dh, hidden, pool,
+             N, Cc, Wd, dw1, db1, dw2, db2);
   MD_CHECK_LAUNCH();
   MD_KLAUNCH(k_row_elem<5>, dim3(elem_blocks(n)), dim3(256), 0, s, a, dout, gate, (const float*)dpool, thw, n, da);
   MD_CHECK_LAUNCH();

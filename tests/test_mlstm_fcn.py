@@ -121,3 +121,10 @@ def test_cfg1_batch32_head_is_composed_from_units():
             assert p.grad is None or float(p.grad.abs().max()) < 1e-3 * gmax, k
             continue
         assert rel(p.grad, r) < 3e-3, (k, rel(p.grad, r))
+    # eval mode through the composed head (running statistics, folded Linear bias)
+    m.eval()
+    sd_eval = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        got = m(x.cuda()).cpu()
+        ref_eval = om.mlstm_fcn_forward(x, sd_eval, kernel_size=3, stride=1, lstm_n_layers=4, bidirectional=True, alpha=0.01, training=False)
+    assert float((got - ref_eval).abs().max()) <= 1e-3 * max(1.0, float(ref_eval.abs().max()))

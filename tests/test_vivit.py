@@ -161,3 +161,20 @@ def test_single_head_identity_projection_and_long_sequences():
     assert float((got.cpu() - ref).abs().max()) < 3e-6
     with pytest.raises(RuntimeError):
         AttentionFunction.apply(torch.randn(1, 1200, 3 * D).cuda(), None, H, None, True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C", [(4, 8192), (3, 5000), (2100, 96), (4, 100)])
+def test_bias_vector_gradient_paths(N, C):
+    """md_channel_bias_* with L = 1 in its three reduction forms: one thread per entry (a table broadcast over few rows: ViViT's
+    positional embedding), two-level column sums (many rows: Linear biases over all tokens), one workgroup per channel (small)."""
+    from src.models._unit import _ChannelBias
+    torch.manual_seed(N + C)
+    x = torch.randn(N, C, 1); b = torch.randn(C); d = torch.randn(N, C, 1)
+    xg, bg = x.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    out = _ChannelBias.apply(xg, bg)
+    out.backward(d.cuda())
+    assert torch.equal(out.detach().cpu(), x + b[None, :, None])
+    ref = d.double().sum(dim=(0, 2))
+    assert float((bg.grad.cpu().double() - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max())) * max(1.0, N ** 0.5)
+    assert torch.equal(xg.grad.cpu(), d)

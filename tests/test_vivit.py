@@ -178,3 +178,30 @@ def test_bias_vector_gradient_paths(N, C):
     ref = d.double().sum(dim=(0, 2))
     assert float((bg.grad.cpu().double() - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max())) * max(1.0, N ** 0.5)
     assert torch.equal(xg.grad.cpu(), d)
+
+
+@pytest.mark.gpu
+def test_residule_prenorm_feedforward_modules_standalone():
+    """The small wrapper classes of ViViT.py (:12-47) used on their own, as a caller composing a custom Transformer would:
+    Residule(PreNorm(dim, FeedForward)) == ff(norm(x)) + x, forward and backward, against PyTorch on the CPU."""
+    from src.models.ViViT import FeedForward, PreNorm, Residule
+    torch.manual_seed(3)
+    blk = Residule(PreNorm(24, FeedForward(24, 40, dropout=0.0)))
+    with torch.no_grad():
+        blk.fn.norm.weight.uniform_(0.5, 1.5); blk.fn.norm.bias.normal_(0, 0.3)
+    x = torch.randn(5, 7, 24); d = torch.randn(5, 7, 24)
+    xr = x.clone().requires_grad_(True)
+    ff = blk.fn.fn.net
+    h = F.layer_norm(xr, (24,), blk.fn.norm.weight, blk.fn.norm.bias, 1e-5)
+    ref = F.linear(F.gelu(F.linear(h, ff[0].weight, ff[0].bias)), ff[3].weight, ff[3].bias) + xr
+    ref.backward(d)
+    ref_grads = {k: p.grad.clone() for k, p in blk.named_parameters()}
+    blk.zero_grad()
+    blk.cuda().train()
+    xg = x.cuda().requires_grad_(True)
+    out = blk(xg)
+    out.backward(d.cuda())
+    assert float((out.detach().cpu() - ref.detach()).abs().max()) < 2e-5
+    assert float((xg.grad.cpu() - xr.grad).abs().max()) < 5e-5
+    for k, p in blk.named_parameters():
+        assert float((p.grad.cpu() - ref_grads[k]).abs().max()) <= 1e-4 * max(1.0, float(ref_grads[k].abs().max())), k

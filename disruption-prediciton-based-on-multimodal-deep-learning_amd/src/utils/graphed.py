@@ -6,10 +6,10 @@ optimizer step stays outside.  Requirements, as for any captured step: fixed inp
 the step, random masks only from torch's device generator (capture-aware); the NoiseLayer of the 0D encoders, which draws from
 the CPU generator as the reference does, is switched to a pinned staging buffer that is refilled before every replay.  Gradients live in static tensors that the graph overwrites on every replay.
 Observed on this stack (ROCm 7.2, torch 2.10): if the model has already run forward + backward on the LEGACY DEFAULT stream in
-the process, ending the capture crashes inside the runtime; steps run on any other stream beforehand are fine.  Probed so far: a plain torch
-model, single operators of this library, and a small SlowFast (8 frames, 64 x 64) all capture fine after default-stream steps; the
-full-size SlowFast (32 frames, 224 x 224) does not - so it is size dependent (large-LDS / eight-wave kernel variants or large
-allocations); not root-caused yet.  Construct the GraphedStep first, or keep eager work under ``torch.cuda.stream(side)``.
+the process, ending the capture crashes inside the runtime; steps run on any other stream beforehand are fine.  Reproducer: ``SF_GRAPH=1 SF_GRAPH_DEFAULT=1 python tools/slowfast_smoke.py 4`` (five eager
+full-size SlowFast steps on the default stream, then the capture) segfaults in ``capture_end``; simplified probes - a plain torch
+model, single operators of this library, small and full-size SlowFast with two default-stream steps before the capture - all
+capture fine, so the trigger is narrower than "any default-stream use" and is not root-caused yet.  Construct the GraphedStep first, or keep eager work under ``torch.cuda.stream(side)``.
 """
 from typing import Callable, Sequence
 

@@ -15,7 +15,7 @@ x = torch.randn(B, 3, 32, 224, 224, device=dev) * 50
 y = (torch.arange(B) % 2).to(dev)
 # with SF_GRAPH the eager reference runs on a side stream: a HIP-graph capture after model steps on the legacy default stream
 # crashes in hipStreamEndCapture on this stack (see src/utils/graphed.py)
-_side = torch.cuda.Stream() if os.environ.get('SF_GRAPH') else None
+_side = torch.cuda.Stream() if (os.environ.get('SF_GRAPH') and not os.environ.get('SF_GRAPH_DEFAULT')) else None
 if _side is not None:
     _side.wait_stream(torch.cuda.current_stream()); torch.cuda.set_stream(_side)
 def step():

@@ -5,11 +5,11 @@ every kernel of this library is launched on torch's current stream, so stream ca
 optimizer step stays outside.  Requirements, as for any captured step: fixed input shapes, no host synchronisation inside
 the step, random masks only from torch's device generator (capture-aware); the NoiseLayer of the 0D encoders, which draws from
 the CPU generator as the reference does, is switched to a pinned staging buffer that is refilled before every replay.  Gradients live in static tensors that the graph overwrites on every replay.
-Observed on this stack (ROCm 7.2, torch 2.10): if the model has already run forward + backward on the LEGACY DEFAULT stream in
-the process, ending the capture crashes inside the runtime; steps run on any other stream beforehand are fine.  Reproducer: ``SF_GRAPH=1 SF_GRAPH_DEFAULT=1 python tools/slowfast_smoke.py 4`` (five eager
-full-size SlowFast steps on the default stream, then the capture) segfaults in ``capture_end``; simplified probes - a plain torch
-model, single operators of this library, small and full-size SlowFast with two default-stream steps before the capture - all
-capture fine, so the trigger is narrower than "any default-stream use" and is not root-caused yet.  Construct the GraphedStep first, or keep eager work under ``torch.cuda.stream(side)``.
+Observed on this stack (ROCm 7.2, torch 2.10): ending the capture segfaults inside the runtime when an output or loss tensor that
+still carries its grad_fn from an EARLIER EAGER step on the legacy default stream is alive during the capture (probed on the
+full-size SlowFast: one such step is enough; dropping the reference or ``.detach()``-ing it, or having run the eager step on any
+other stream, avoids it; reproducer: ``SF_GRAPH=1 SF_GRAPH_DEFAULT=1 python tools/slowfast_smoke.py 4``).  So: construct the
+GraphedStep first, or keep eager work under ``torch.cuda.stream(side)``, or detach / drop what earlier steps returned.
 """
 from typing import Callable, Sequence
 

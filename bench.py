@@ -45,7 +45,7 @@ def synth_batch(device, seed):
     return x.to(device), y.to(device)
 
 
-def cpu_baseline(steps=2, warmup=1):
+def cpu_baseline(steps=5, warmup=2):
     """The oracle (CPU restatement of the reference, oracle/) timed on the host cores: same step definition,
     same shapes, bounded sample.  Reported beside the GPU number; never the thing optimised."""
     from oracle import losses as ol, r2plus1d as orc, step as ostep
@@ -188,13 +188,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # per-step trace: one (timing) event per step on the compute stream + the host time at which the step was queued;
+    # both are read after the timed region (no synchronisation inside it)
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    host_t = [0.0] * (args.steps + 1)
     fence()
     t0 = time.perf_counter()
+    step_ev[0].record(); host_t[0] = t0
     for i in range(args.steps):
         events_for(i)
         step()
+        step_ev[i + 1].record(); host_t[i + 1] = time.perf_counter()
     fence()
     dt = time.perf_counter() - t0
+    gpu_ms = sorted(step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps))
+    host_ms = sorted((host_t[i + 1] - host_t[i]) * 1e3 for i in range(args.steps))
+    first_gpu_ms = step_ev[0].elapsed_time(step_ev[1])
+
+    def pct(v, q):
+        return round(v[min(len(v) - 1, int(q * len(v)))], 4)
+    step_trace = {"gpu_ms": {"first": round(first_gpu_ms, 4), "p10": pct(gpu_ms, 0.1), "median": pct(gpu_ms, 0.5), "p90": pct(gpu_ms, 0.9),
+                             "max": round(gpu_ms[-1], 4)},
+                  "host_queue_ms": {"p10": pct(host_ms, 0.1), "median": pct(host_ms, 0.5), "p90": pct(host_ms, 0.9),
+                                    "max": round(host_ms[-1], 4)},
+                  "note": "gpu_ms = interval between the per-step events on the compute stream; host_queue_ms = host time to queue one step"}
     prof = plan.profile_read()
     plan.profile_enable(False)
     if float(finite.item()) != 1.0:
@@ -223,8 +240,17 @@ def main():
             dom, d_ms, d_n, d_fl = "k_conv_patch", g_ms, g_n, g_fl
         else:
             dom, d_ms, d_n, d_fl = "k_wgrad_patch", w_ms, w_n, w_fl
-        achieved = d_fl / (d_ms * 1e-3) / 1e12 if d_ms > 0 else 0.0
+        mfma_tflops = d_fl / (d_ms * 1e-3) / 1e12 if d_ms > 0 else 0.0
         traffic, traffic_note = pmc_traffic(dom)
+        # this path is HBM-bound.  Algorithmic bytes of one launch of the dominant family = the family's share
+        # of the step's ideal-fusion conv I/O (951.9 MB/clip fp32: forward 1/3, data gradient 1/3, weight gradient 1/3)
+        # divided by its launches per step; achieved = those bytes / the average launch duration measured live with HIP events.
+        fam_share = (2.0 / 3.0) if dom == "k_conv_patch" else (1.0 / 3.0)
+        launches_per_step = d_n / max(1, sampled[0])
+        alg_bytes_per_launch = fam_share * ALG_BYTES_PER_CLIP_FP32 * B_PER_GPU / max(1.0, launches_per_step)
+        avg_launch_s = d_ms * 1e-3 / max(1, d_n)
+        achieved = alg_bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        step_gbs = value / world * ALG_BYTES_PER_CLIP_FP32 / 1e9
         out = {
             "metric": "clips/sec (fwd+bwd) R2Plus1D T=21 128x128", "value": round(value, 2), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
@@ -234,17 +260,22 @@ def main():
             "config": {"workload": "R2Plus1D layer_sizes=[1,2,2,1] alpha=0.01, per-GPU clips (8,3,21,128,128) fp32, "
                                    "forward+FocalLoss(gamma=2)+backward+clip_grad_norm(1.0)+AdamW(2e-4), BN in train mode",
                        "per_gpu_batch": B_PER_GPU, "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": round(PEAK_SPLIT_TFLOPS, 1), "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_SPLIT_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
-                         "kernel": dom,
-                         "peak_note": "2500 TFLOP/s dense 16-bit MFMA / 3 products per multiply; achieved = algorithmic FLOPs",
-                         "launches": int(d_n), "avg_launch_ms": round(d_ms / max(1, d_n), 5),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
+                         "kernel": dom, "launches": int(d_n), "avg_launch_ms": round(d_ms / max(1, d_n), 5),
+                         "alg_bytes_per_launch": round(alg_bytes_per_launch),
                          "event_sampling": f"every {EVENT_EVERY}th timed step ({sampled[0]} of {args.steps})",
-                         "alg_flop_per_launch": d_fl / max(1, d_n)},
+                         "whole_step_achieved": round(step_gbs, 1), "whole_step_frac": round(step_gbs / PEAK_HBM_GBS, 4),
+                         "whole_step_note": "clips/s x 951.9e6 B (SURVEY 8(d), fp32 storage) against 8000 GB/s",
+                         "mfma_view": {"achieved_tflops": round(mfma_tflops, 3), "peak_tflops": round(PEAK_SPLIT_TFLOPS, 1),
+                                       "frac": round(mfma_tflops / PEAK_SPLIT_TFLOPS, 4),
+                                       "note": "algorithmic FLOPs of the family / event time against 2500/3 TFLOP/s "
+                                               "(dense 16-bit MFMA peak / 3 products per multiply)"}},
             "kernels": kern,
             "whole_step": {"alg_tflops": round(value / world * ALG_FLOP_PER_CLIP / 1e12, 2),
-                           "alg_hbm_gbs_fp32": round(value / world * ALG_BYTES_PER_CLIP_FP32 / 1e9, 1),
-                           "hbm_frac_of_8TBs": round(value / world * ALG_BYTES_PER_CLIP_FP32 / 1e9 / PEAK_HBM_GBS, 4)},
+                           "alg_hbm_gbs_fp32": round(step_gbs, 1),
+                           "hbm_frac_of_8TBs": round(step_gbs / PEAK_HBM_GBS, 4)},
+            "step_trace": step_trace,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -156,7 +156,8 @@ __global__ void k_bn_eval_params(int C, int Cp, const float* __restrict__ gamma,
 
 // ---------------------------------------------------------------- BatchNorm backward
 // g = dA * leaky'_main(pre_main); closing form: dS = dZ * leaky'_alpha(act(skip) + act(main)), g = dS * leaky'(pre).
-template <bool APPLY>
+// GIN: dA already holds g (the fused reduction of the consumer's data gradient multiplied by leaky' on the way out).
+template <bool APPLY, bool GIN = false>
 __global__ __launch_bounds__(256) void k_bn_bwd(const float* __restrict__ dA, View main, View skip, int has_skip,
                                                 float alpha, const float* __restrict__ mean,
                                                 const float* __restrict__ invstd, const float* __restrict__ coef,
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd(const float* __restrict__ dA, Vi
         d = mul4(d, make_float4(md_dleaky(sum.x, alpha), md_dleaky(sum.y, alpha), md_dleaky(sum.z, alpha), md_dleaky(sum.w, alpha)));
         if (APPLY) *(float4*)(dS + o) = d;
       }
-      const float4 gq = mul4(d, dact_of(main, pre));
+      const float4 gq = GIN ? d : mul4(d, dact_of(main, pre));
       const float4 xh = make_float4((raw.x - mu.x) * is.x, (raw.y - mu.y) * is.y, (raw.z - mu.z) * is.z, (raw.w - mu.w) * is.w);
       if (APPLY) {
         float4 r;
@@ -400,6 +401,17 @@ extern "C" int md_bn_bwd_apply(const float* dA, const MdActView* main, const MdA
   MD_KLAUNCH(k_bn_bwd<true>, dim3(stream_blocks(rows, C4)), dim3(256), 0, (hipStream_t)stream, dA, to_view(main),
                      to_view(skip), skip != nullptr ? 1 : 0, alpha, mean, invstd, coef, rows, C4, (float*)nullptr,
                      d_raw, dS);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+extern "C" int md_bn_bwd_apply_g(const float* g, const MdActView* main, const float* mean, const float* invstd,
+                                 const float* coef, int64_t rows, int32_t C, float* d_raw, void* stream) {
+  if (!g || !main || !main->data || !main->scale || !mean || !invstd || !coef || !d_raw) return MD_ERR_NULL;
+  int rc = check_rows(rows, C); if (rc) return rc;
+  const int C4 = md_cpad(C) / 4;
+  MD_KLAUNCH((k_bn_bwd<true, true>), dim3(stream_blocks(rows, C4)), dim3(256), 0, (hipStream_t)stream, g, to_view(main),
+             to_view(nullptr), 0, 1.f, mean, invstd, coef, rows, C4, (float*)nullptr, d_raw, (float*)nullptr);
   MD_CHECK_LAUNCH();
   return MD_OK;
 }

@@ -63,8 +63,10 @@ const PatchPlan* patch_lookup(const MdConvDesc* d, int dgrad);     // nullptr wh
 size_t patch_wpack_floats(const PatchPlan* p);
 int patch_blocks(const PatchPlan* p);
 int patch_pack(const MdConvDesc* d, int dgrad, const PatchPlan* p, const float* w, float* out, hipStream_t s);
+struct PersBwd;     // fused BatchNorm-backward reduction of a data gradient (patch_common.h)
 int patch_launch(const PatchPlan* p, const float* src, const float* ps, const float* psh, float slope, const float* wp,
-                 float* dst, float* stat, int accumulate, hipStream_t s);
+                 float* dst, float* stat, int accumulate, hipStream_t s, const PersBwd* bw = nullptr);
+bool patch_can_fuse(const PatchPlan* p);
 
 struct WgradPlan;
 const WgradPlan* wgrad_lookup(const MdConvDesc* d);

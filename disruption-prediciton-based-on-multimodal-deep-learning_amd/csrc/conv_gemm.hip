@@ -11,6 +11,7 @@
 // k = 16*s + 4*g + e to MFMA e, identically for A and B, which is a permutation of the K axis and
 // leaves the product unchanged.  LDS row pitch 40 floats makes those b128 reads bank-conflict free.
 #include "common.h"
+#include "patch_common.h"
 
 #define BM 128          // destination rows per workgroup
 #define KB 32           // K depth per LDS stage (floats)
@@ -508,6 +509,25 @@ extern "C" int md_conv_dgrad(const MdConvDesc* d, const float* dy_raw, const flo
       linear_split_launch(0, dy_raw, g.M, g.Kc * 4, wpack_dgrad, g.Kp, g.N16, dx, g.Cpo, accumulate, (hipStream_t)stream) == MD_OK)
     return MD_OK;
   return launch_gemm(g, dy_raw, nullptr, nullptr, 1.f, wpack_dgrad, dx, nullptr, accumulate, (hipStream_t)stream);
+}
+
+extern "C" int32_t md_conv_dgrad_bnred_blocks(const MdConvDesc* d) {
+  if (check_desc(d) != MD_OK) return 0;
+  const PatchPlan* pp = patch_lookup(d, 1);
+  return (pp && patch_can_fuse(pp)) ? patch_blocks(pp) : 0;
+}
+extern "C" int md_conv_dgrad_bnred(const MdConvDesc* d, const float* dy_raw, const float* wpack_dgrad, float* g_out,
+                                   int accumulate, const MdActView* y_view, const float* mean, const float* invstd,
+                                   float* partial, void* stream) {
+  int rc = check_desc(d);
+  if (rc != MD_OK) return rc;
+  if (!dy_raw || !wpack_dgrad || !g_out || !y_view || !y_view->data || !y_view->scale || !y_view->shift || !mean || !invstd || !partial)
+    return MD_ERR_NULL;
+  const PatchPlan* pp = patch_lookup(d, 1);
+  if (!pp || !patch_can_fuse(pp)) return MD_ERR_UNSUPPORTED;
+  PersBwd bw; bw.yraw = y_view->data; bw.scale = y_view->scale; bw.shift = y_view->shift; bw.mean = mean; bw.invstd = invstd;
+  bw.slope = y_view->slope;
+  return patch_launch(pp, dy_raw, nullptr, nullptr, 1.f, wpack_dgrad, g_out, partial, accumulate, (hipStream_t)stream, &bw);
 }
 
 extern "C" size_t md_conv_wgrad_workspace_floats(const MdConvDesc* d) {

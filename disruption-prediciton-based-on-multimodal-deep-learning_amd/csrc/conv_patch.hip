@@ -18,96 +18,7 @@
 #include "common.h"
 #include <cstdlib>
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-#define PM 128            // rows (output pixels) per workgroup
-#define PNREP 9           // up to 144 destination channels per workgroup
-#define PB_PITCH 160      // B tile row pitch (bytes): 8 chunks of 16 B + pad, (160/16) % 4 == 2
-#define PMAXC 320
-
-struct PGeom {
-  int Ts, Hs, Ws, Cps;      // source dims, channel pitch (floats)
-  int Td, Hd, Wd, Cpd;      // destination dims, channel pitch (floats)
-  int kh, kw, khw, taps;
-  int org_t, org_h, org_w;  // source coordinate = box origin * stride + org + patch coordinate
-  int st, sh, sw;           // stride of the (forward) convolution; 1 for the data gradient
-  int strided;              // 1: data gradient of a strided convolution (per-tap divisibility test)
-  int dst_, dsh_, dsw_;     // the convolution's stride (strided data gradient)
-  int lt, lh, lw, oddmask;  // log2 strides; packed mask of the low bits that must be zero
-  int kt, padt, padh, padw;
-  int zero_off;             // byte offset of the all-zero pixel
-  int bt, by, bx, byx;      // output box
-  int nbt, nby, nbx;        // boxes per clip
-  int pt, py, px, pyx, P;   // patch dims
-  int C8;                   // 8-channel chunks per pixel in LDS
-  int ppitch;               // LDS bytes per patch pixel (hi array); lo array follows at lo_off
-  int lo_off;
-  int Kc8;                  // taps * C8
-  int nstages;              // ceil(Kc8 / 8): 64 k per stage
-  int N16;
-  unsigned magicC8;         // floor(2^32 / C8) + 1 : exact item / C8 for item < 2^16 (0 when the divisor is 1)
-  unsigned m_pyx, m_px, m_byx, m_bx, m_khw, m_kw;   // same for the table decodes (all indices < 2^16)
-  unsigned src_bytes, dst_bytes;                      // tensor sizes for the buffer descriptors (< 2 GiB)
-  int Tdf, Hdf, Wdf;        // full destination dims; destination coordinate = box coordinate * dm + dp
-  int dmt, dmh, dmw, dpt, dph, dpw;   // (one residue class of a strided data gradient writes a strided subset)
-  int off_b, off_koffs, off_rows, off_pixg, off_scale;   // LDS byte offsets
-  int pack2, pk_shift, pk_kw; // pixel-pair reinterpretation of a <=4-channel, W-stride-2 input (see patch_build)
-};
-
-__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
-  f32x2 v = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned pk_f16(float a, float b) {
-  f32x2 v = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
-}
-// fp16 split: hi = fp16(x) (11 significant bits), lo = fp16(x - hi) -> 22 bits, i.e. fp32-level products with
-// three MFMAs.  fp16 subnormals are kept (HIP kernels run with float_denorm_mode_16_64 = preserve), so the
-// absolute error of hi+lo is <= max(2^-23 |x|, 2^-25); |x| must stay below 65504 (activations and weights do).
-__device__ __forceinline__ void split8_f16(const float* v, uint4& hi, uint4& lo) {
-  unsigned h[4], l[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    h[i] = pk_f16(v[2 * i], v[2 * i + 1]);
-    const f16x2 hv = __builtin_bit_cast(f16x2, h[i]);
-    l[i] = pk_f16(v[2 * i] - (float)hv[0], v[2 * i + 1] - (float)hv[1]);
-  }
-  hi = make_uint4(h[0], h[1], h[2], h[3]);
-  lo = make_uint4(l[0], l[1], l[2], l[3]);
-}
-// split 8 floats into packed bf16 hi and lo (4 dwords each)
-__device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
-  unsigned h[4], l[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    h[i] = pk_bf16(v[2 * i], v[2 * i + 1]);
-    const float h0 = __builtin_bit_cast(float, h[i] << 16), h1 = __builtin_bit_cast(float, h[i] & 0xffff0000u);
-    l[i] = pk_bf16(v[2 * i] - h0, v[2 * i + 1] - h1);
-  }
-  hi = make_uint4(h[0], h[1], h[2], h[3]);
-  lo = make_uint4(l[0], l[1], l[2], l[3]);
-}
-
-// x / d for 0 <= x, x * d < 2^32, with magic = floor(2^32 / d) + 1 (0 encodes d == 1)
-__device__ __forceinline__ int mdiv(int x, unsigned magic) { return magic ? (int)__umulhi((unsigned)x, magic) : x; }
-
-// Raw buffer descriptor over a whole tensor (< 2 GiB): loads at an out-of-range offset return zeros and stores there
-// are dropped, so edge handling needs no branches and no 64-bit address arithmetic.  MD_OOB = 2 GiB is out of range
-// for every tensor we accept and cannot wrap around when an instruction offset is added.
-#define MD_OOB 0x80000000u
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned off) {
-  // (bit_cast of the whole vector: indexing the builtin's result element-wise is miscompiled into one dword load)
-  const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
-  return make_float4(f[0], f[1], f[2], f[3]);
-}
+#include "patch_common.h"
 
 // Stage `npix` pixels x `C8` 8-channel chunks of a channels-last fp32 tensor into an LDS image
 // [pixel][C8 chunks] (pixel pitch `pitch` bytes; hi array at img, lo array at img + lo_off).
@@ -143,10 +54,15 @@ __device__ __forceinline__ void stage_image(__amdgpu_buffer_rsrc_t src, int Cpit
       float v[8] = {va[u].x, va[u].y, va[u].z, va[u].w, vb[u].x, vb[u].y, vb[u].z, vb[u].w};
       if (prologue) {
         const float keep = (pix[u] & 0x20000000) ? 0.f : 1.f;       // padding stays zero after the activation
+        // (scale/shift of the channel padding are zero in LDS: a padded channel is 0 in memory and stays leaky(0*0+0) = 0,
+        // so no per-element "does this channel exist" test -- it compiled into eight dependent LDS round trips per item)
         const float* sc = sScale + c0 + c8s[u] * 8; const float* sh = sShift + c0 + c8s[u] * 8;
-        const int nv = min(8, (cvalid4 - c8s[u] * 2) * 4);          // channels of this chunk that exist
+        const f32x4 sc0 = *(const f32x4*)sc, sc1 = *(const f32x4*)(sc + 4), sh0 = *(const f32x4*)sh, sh1 = *(const f32x4*)(sh + 4);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = e < nv ? md_leaky(fmaf(v[e], sc[e], sh[e]), pslope) * keep : 0.f;
+        for (int e = 0; e < 4; ++e) {
+          v[e] = md_leaky(fmaf(v[e], sc0[e], sh0[e]), pslope) * keep;
+          v[4 + e] = md_leaky(fmaf(v[4 + e], sc1[e], sh1[e]), pslope) * keep;
+        }
       }
       uint4 hi, lo;
       if (F16) split8_f16(v, hi, lo); else split8(v, hi, lo);
@@ -155,12 +71,6 @@ __device__ __forceinline__ void stage_image(__amdgpu_buffer_rsrc_t src, int Cpit
       *(uint4*)(d + lo_off) = lo;
     }
   }
-}
-
-template <bool F16>
-__device__ __forceinline__ f32x4 mma(uint4 a, uint4 b, f32x4 c) {
-  if (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
 // F16 = true: forward convolution, operands split into fp16 halves (activations/weights are O(1) quantities);
@@ -244,7 +154,10 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void k_conv_patch(
     }
     sK[q] = ko;
   }
-  if (prologue) for (int c = t; c < g.Cps; c += NT) { const int cs = g.pack2 ? (c & 3) : c; sScale[c] = pscale[cs]; sShift[c] = pshift[cs]; }
+  if (prologue) for (int c = t; c < g.C8 * 8; c += NT) {       // zero for the channel padding up to whole 8-channel chunks
+    const int cs = g.pack2 ? (c & 3) : c;
+    sScale[c] = c < g.Cps ? pscale[cs] : 0.f; sShift[c] = c < g.Cps ? pshift[cs] : 0.f;
+  }
 
   // ---- B tile prefetch (registers): [stage][hi|lo][N16][8 chunks] uint4, this block's rows n0..n0+ncols.
   // Loads are unconditional (clamped index) so that the prefetch stays a straight run of global loads.
@@ -460,21 +373,21 @@ static int pitch_for(int C8) {          // smallest 16*(4m+2) >= 16*C8
 // to the LDS budget: `maxP` patch pixels at most, and a 25% penalty once the patch exceeds `softP` pixels (the size
 // up to which two workgroups still fit on one CU).  dgrad_s > 1: patch of a strided data gradient (source shrinks).
 static bool choose_box(int T, int H, int W, int kt, int kh, int kw, int st, int sh, int sw, int dgrad, int maxP, int softP,
-                       int* bt, int* by, int* bx) {
+                       int* bt, int* by, int* bx, int pm = PM) {
   double best = 1e300;
   bool found = false;
   auto pdim = [&](int b, int k, int s) { return dgrad ? (b + k - 2) / s + 2 : (b - 1) * s + k; };
   for (int t = 1; t <= T && t <= 32; ++t) {
-    for (int x = 1; x <= 128; x *= 2) {
+    for (int x = 1; x <= pm; x *= 2) {
       const int xe = x >= W ? W : x;     // powers of two, and the full width
-      int ymax = PM / (t * xe);
+      int ymax = pm / (t * xe);
       if (ymax >= 1) {
         if (ymax > H) ymax = H;
         for (int y = ymax; y >= 1; y = (y > 4 ? y / 2 : y - 1)) {
           const double boxes = (double)md_cdiv(T, t) * md_cdiv(H, y) * md_cdiv(W, xe);
           const long long patch = (long long)pdim(t, kt, st) * pdim(y, kh, sh) * pdim(xe, kw, sw);
           if (patch > maxP) continue;
-          double cost = boxes * (PM + 0.6 * (double)patch);
+          double cost = boxes * (pm + 0.6 * (double)patch);
           if (patch > softP) cost *= 1.25;
           if (cost < best) { best = cost; *bt = t; *by = y; *bx = xe; found = true; }
         }
@@ -492,7 +405,10 @@ static int ilog2_exact(int v) { int l = 0; while ((1 << l) < v) ++l; return (1 <
 // only the taps tap0, tap0 + s, ... (kc of them); over the class grid j this is a unit-stride correlation.
 struct ClassSpec { int c[3], tap0[3], kc[3], e[3]; };
 
-static bool patch_build(const MdConvDesc* d, int dgrad, PGeom* out, size_t* lds_bytes, const ClassSpec* cls = nullptr) {
+// pers_wgs > 0: geometry for the persistent kernel (conv_pers.hip) at that many workgroups per CU -- the LDS budget then
+// holds the whole packed weight operand instead of one streamed stage.
+static bool patch_build(const MdConvDesc* d, int dgrad, PGeom* out, size_t* lds_bytes, const ClassSpec* cls = nullptr,
+                        int pers_wgs = 0) {
   PGeom g;
   const bool sdg = !cls && dgrad && (d->st != 1 || d->sh != 1 || d->sw != 1);      // strided data gradient, tap-test form
   g.strided = sdg ? 1 : 0;
@@ -540,6 +456,8 @@ static bool patch_build(const MdConvDesc* d, int dgrad, PGeom* out, size_t* lds_
   }
   g.C8 = (g.Cps + 7) / 8;
   g.ppitch = pitch_for(g.C8);
+  // persistent form: hi and lo chunks of a pixel share one pitch ([pixel][hi C8 | lo C8 | pad]) -- smaller than two padded arrays
+  if (pers_wgs) g.ppitch = pitch_for(2 * g.C8);
   g.Kc8 = g.taps * g.C8;
   g.nstages = md_cdiv(g.Kc8, 8);
   g.N16 = md_round_up(cd, 16);
@@ -554,19 +472,23 @@ static bool patch_build(const MdConvDesc* d, int dgrad, PGeom* out, size_t* lds_
   const int nchunks_ = md_cdiv(g.N16, PNREP * 16);
   const int npb_ = md_round_up(md_cdiv(g.N16, nchunks_), 16);
   // LDS: everything but the patch
-  const size_t fixed = (size_t)2 * npb_ * PB_PITCH + (size_t)g.nstages * 8 * 4 + (size_t)PM * 16 + 3072 + 2 * PMAXC * 4 + 1024;
-  const size_t cap = 160 * 1024;
+  if (pers_wgs && (sdg || g.N16 > 128 || g.N16 < 32)) return false;
+  const int pm = PM;
+  const size_t fixed = pers_wgs ? pers_bres_bytes(g.Kc8, g.N16) + pers_fixed_bytes(g.Cps, g.N16) + (size_t)g.nstages * 8 * 4
+                                : (size_t)2 * npb_ * PB_PITCH + (size_t)g.nstages * 8 * 4 + (size_t)PM * 16 + 3072 + 2 * PMAXC * 4 + 1024;
+  const size_t cap = (size_t)160 * 1024;
   if (fixed + 4096 > cap) return false;
-  const long long per_px = (long long)2 * g.ppitch + 4;
+  const long long per_px = pers_wgs ? (long long)2 * g.ppitch : (long long)2 * g.ppitch + 4;     // persistent: two patches (one per team), hi+lo in one pitch
   long long maxP = (long long)(cap - fixed) / per_px - 2;
   static const int soft_kb = getenv("MD_LDS_SOFT_KB") ? atoi(getenv("MD_LDS_SOFT_KB")) : 80;   // target LDS per workgroup
-  long long softP = ((long long)soft_kb * 1024 - (long long)fixed) / per_px - 2;
-  const long long idx_cap = 65535 / g.C8;              // item index must stay below 2^16 for the magic division
+  long long softP = pers_wgs ? maxP : ((long long)soft_kb * 1024 - (long long)fixed) / per_px - 2;
+  long long idx_cap = 65535 / g.C8;              // item index must stay below 2^16 for the magic division
+  if (pers_wgs && idx_cap > (long long)PERS_MAXI * 256 / g.C8) idx_cap = (long long)PERS_MAXI * 256 / g.C8;   // register-staged items (per team)
   if (maxP > idx_cap) maxP = idx_cap;
   if (softP < 1) softP = 1;
   if (maxP < 1) return false;
   if (!choose_box(g.Td, g.Hd, g.Wd, kt_eff, kh_eff, kw_eff, sdg ? d->st : g.st, sdg ? d->sh : g.sh, sdg ? d->sw : sw_eff, sdg,
-                  (int)maxP, (int)softP, &g.bt, &g.by, &g.bx)) return false;
+                  (int)maxP, (int)softP, &g.bt, &g.by, &g.bx, pm)) return false;
   g.byx = g.by * g.bx;
   g.nbt = md_cdiv(g.Td, g.bt); g.nby = md_cdiv(g.Hd, g.by); g.nbx = md_cdiv(g.Wd, g.bx);
   if (!sdg) {
@@ -579,6 +501,7 @@ static bool patch_build(const MdConvDesc* d, int dgrad, PGeom* out, size_t* lds_
   g.m_khw = magic_of(g.khw); g.m_kw = magic_of(g.kw);
   g.zero_off = g.P * g.ppitch;                          // one all-zero pixel behind the patch (invalid taps read it)
   g.lo_off = ((g.P + 1) * g.ppitch + 15) & ~15;
+  if (pers_wgs) g.lo_off = g.C8 * 16;
   size_t off = (size_t)2 * g.lo_off;
   const size_t red = (size_t)4 * 2 * PNREP * 16 * 4;      // epilogue reduction scratch aliases the patch
   if (off < red) off = red;
@@ -587,17 +510,50 @@ static bool patch_build(const MdConvDesc* d, int dgrad, PGeom* out, size_t* lds_
   g.off_rows = (int)off; off += (size_t)PM * 16 + 3072;      // >= 4608 B: also the persistent kernel's reduction scratch
   g.off_pixg = (int)off; off += (size_t)((g.P * 4 + 15) & ~15);
   g.off_scale = (int)off; off += (size_t)2 * PMAXC * 4;
-  if (off > cap) return false;
+  if (!pers_wgs && off > cap) return false;
+  if (pers_wgs && (g.pt >= 64 || g.py >= 512 || g.px >= 512 || g.bt >= 256 || g.by >= 256 || g.bx >= 256)) return false;
   if (getenv("MD_PLAN_PRINT"))
-    fprintf(stderr, "patch %s %d->%d k%d%d%d s%d%d%d dst %dx%dx%d: box %dx%dx%d patch %dx%dx%d=%d C8=%d stages=%d lds=%zu\n",
-            dgrad ? (cls ? "dgrad-class" : "dgrad") : "fwd", d->Cin, d->Cout, d->kt, d->kh, d->kw, d->st, d->sh, d->sw, g.Td, g.Hd,
+    fprintf(stderr, "patch%s %s %d->%d k%d%d%d s%d%d%d dst %dx%dx%d: box %dx%dx%d patch %dx%dx%d=%d C8=%d stages=%d lds=%zu\n",
+            pers_wgs ? "(persistent)" : "", dgrad ? (cls ? "dgrad-class" : "dgrad") : "fwd", d->Cin, d->Cout, d->kt, d->kh, d->kw, d->st, d->sh, d->sw, g.Td, g.Hd,
             g.Wd, g.bt, g.by, g.bx, g.pt, g.py, g.px, g.P, g.C8, g.nstages, off);
   *out = g; *lds_bytes = off;
   return true;
 }
 
-struct PatchClass { PGeom g; size_t lds; size_t wp_off; ClassSpec spec; };     // wp_off: floats into the packed operand
-struct PatchPlan { PGeom g; size_t lds; int N; int dgrad; int ncls; PatchClass cls[8]; };
+#include <atomic>
+static std::atomic<int> g_pers_grid{0};     // > 0: test override of the persistent kernels' grid (md_set_pers_grid)
+extern "C" int md_set_pers_grid(int n) { return g_pers_grid.exchange(n > 0 ? n : 0); }
+struct PersVariant { bool on; PersGeom pg; size_t lds; int grid; };           // persistent-kernel form of the same launch
+struct PatchClass { PGeom g; size_t lds; size_t wp_off; ClassSpec spec; PersVariant pers; };     // wp_off: floats into the packed operand
+struct PatchPlan { PGeom g; size_t lds; int N; int dgrad; int ncls; PatchClass cls[8]; PersVariant pers; };
+
+// Persistent form (conv_pers.hip) of one launch, when the geometry qualifies: the packed weights fit in LDS beside the
+// patch, the box is nearly full, and there are at least as many boxes as resident workgroups.  The packed-weight format
+// (K order, N16) does not depend on the box, so both forms read the same operand.
+static void pers_try(const MdConvDesc* d, int dgrad, const ClassSpec* cls, const PGeom& classic, PersVariant* pv) {
+  pv->on = false;
+  static const int off = getenv("MD_PERS") && atoi(getenv("MD_PERS")) == 0;
+  static const int off_f = getenv("MD_PERS_FWD") && atoi(getenv("MD_PERS_FWD")) == 0;
+  static const int off_d = getenv("MD_PERS_DGRAD") && atoi(getenv("MD_PERS_DGRAD")) == 0;
+  if (off || (dgrad ? off_d : off_f)) return;
+  static const int min_rows = getenv("MD_PERS_MIN_ROWS") ? atoi(getenv("MD_PERS_MIN_ROWS")) : 96;
+  const int grid_override = g_pers_grid.load();
+  PGeom g; size_t lds = 0;
+  if (!patch_build(d, dgrad, &g, &lds, cls, 1)) return;
+  if (g.Kc8 != classic.Kc8 || g.N16 != classic.N16 || g.nstages != classic.nstages) return;
+  if (!grid_override && g.bt * g.by * g.bx < min_rows) return;
+  PersGeom pg; pg.g = g;
+  int grid = 0;
+  if (!pers_finish(&pg, &lds, &grid)) return;
+  if (grid_override) grid = grid_override;
+  pg.nboxes = d->N * g.nbt * g.nby * g.nbx;
+  if (pg.nboxes >= 65536 || pg.nboxes < 2 * grid) return;       // at least one box per team
+  pg.nit = md_cdiv(g.P * g.C8, 256);
+  if (pg.nit > PERS_MAXI || (pg.nit > 4 && g.N16 > 48) || g.N16 > 96) return;      // instantiated: <= 6 tiles; 8 items only with <= 3 tiles
+  pg.m_nbx = magic_of(g.nbx); pg.m_nby = magic_of(g.nby); pg.m_nbt = magic_of(g.nbt);
+  pv->on = true; pv->pg = pg; pv->lds = lds; pv->grid = grid;
+  if (getenv("MD_PLAN_PRINT")) fprintf(stderr, "  -> persistent: boxes %d grid %d lds %zu nsteps %d nit %d\n", pg.nboxes, grid, lds, pg.nsteps, pg.nit);
+}
 
 // Strided data gradient by residue classes.  dX[i] = sum over taps with (i + pad - tap) % s == 0 of
 // dY[(i + pad - tap) / s] W[tap].  For i = s*j + c the valid taps are tap0 + s*a, tap0 = (c + pad) % s, a < kc, and the
@@ -627,6 +583,7 @@ static int patch_classes(const MdConvDesc* d, PatchPlan* pp) {
         if (empty) continue;                 // no destination pixel in this class
         PatchClass& pc = pp->cls[n];
         if (!patch_build(d, 1, &pc.g, &pc.lds, &cs)) return 0;
+        pers_try(d, 1, &cs, pc.g, &pc.pers);
         pc.spec = cs; pc.wp_off = off;
         off += (size_t)pc.g.nstages * 2 * pc.g.N16 * 64 / 2;
         ++n;
@@ -651,9 +608,9 @@ const PatchPlan* patch_lookup(const MdConvDesc* d, int dgrad) {
     if ((dgrad && dis_d) || (!dgrad && dis_f)) return nullptr;
   }
   static std::mutex mu;
-  static std::map<std::array<int, 19>, PatchPlan*> cache;    // value nullptr = does not qualify
-  std::array<int, 19> key = {d->N, d->Ti, d->Hi, d->Wi, d->Cin, d->To, d->Ho, d->Wo, d->Cout, d->kt, d->kh, d->kw,
-                             d->st, d->sh, d->sw, d->pt, d->ph, d->pw, dgrad};
+  static std::map<std::array<int, 20>, PatchPlan*> cache;    // value nullptr = does not qualify
+  std::array<int, 20> key = {d->N, d->Ti, d->Hi, d->Wi, d->Cin, d->To, d->Ho, d->Wo, d->Cout, d->kt, d->kh, d->kw,
+                             d->st, d->sh, d->sw, d->pt, d->ph, d->pw, dgrad, g_pers_grid.load()};
   std::lock_guard<std::mutex> lock(mu);
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
@@ -663,11 +620,12 @@ const PatchPlan* patch_lookup(const MdConvDesc* d, int dgrad) {
   if (dgrad && !no_cls && (d->st != 1 || d->sh != 1 || d->sw != 1)) {
     PatchPlan* cp = new PatchPlan();
     cp->ncls = patch_classes(d, cp);
-    if (cp->ncls > 0) { cp->g = cp->cls[0].g; cp->lds = cp->cls[0].lds; cp->N = d->N; cp->dgrad = 1; pp = cp; }
+    if (cp->ncls > 0) { cp->g = cp->cls[0].g; cp->lds = cp->cls[0].lds; cp->N = d->N; cp->dgrad = 1; cp->pers.on = false; pp = cp; }
     else delete cp;
   }
   if (!pp && patch_build(d, dgrad, &g, &lds)) {
     pp = new PatchPlan(); pp->g = g; pp->lds = lds; pp->N = d->N; pp->dgrad = dgrad; pp->ncls = 0;
+    pers_try(d, dgrad, nullptr, g, &pp->pers);
   }
   cache[key] = pp;
   return pp;
@@ -759,7 +717,17 @@ size_t patch_wpack_floats(const PatchPlan* p) {      // 16-bit element count / 2
   const PatchClass& l = p->cls[p->ncls - 1];
   return l.wp_off + (size_t)l.g.nstages * 2 * l.g.N16 * 64 / 2;
 }
-int patch_blocks(const PatchPlan* p) { return p->N * p->g.nbt * p->g.nby * p->g.nbx; }
+static int variant_blocks(const PatchPlan* p, const PGeom& g, const PersVariant& pv) {
+  if (pv.on) return pers_blocks(pv.pg, pv.grid);
+  return p->N * g.nbt * g.nby * g.nbx;
+}
+// rows of the partial-sum buffer written by one launch sequence (all residue classes)
+int patch_blocks(const PatchPlan* p) {
+  if (!p->ncls) return variant_blocks(p, p->g, p->pers);
+  int n = 0;
+  for (int c = 0; c < p->ncls; ++c) n += variant_blocks(p, p->cls[c].g, p->cls[c].pers);
+  return n;
+}
 
 int patch_pack(const MdConvDesc* d, int dgrad, const PatchPlan* p, const float* w, float* out, hipStream_t s) {
   (void)p;
@@ -768,8 +736,14 @@ int patch_pack(const MdConvDesc* d, int dgrad, const PatchPlan* p, const float* 
   return rc ? rc : (handled ? MD_OK : MD_ERR_UNSUPPORTED);
 }
 
-static int patch_launch_one(const PatchPlan* p, const PGeom& g, size_t lds, const float* src, const float* ps, const float* psh,
-                            float slope, const float* wp, float* dst, float* stat, int accumulate, hipStream_t s) {
+static int patch_launch_one(const PatchPlan* p, const PGeom& g, size_t lds, const PersVariant& pv, const float* src, const float* ps,
+                            const float* psh, float slope, const float* wp, float* dst, float* stat, int accumulate,
+                            const PersBwd* bw, hipStream_t s) {
+  if (pv.on) {
+    PersBwd none; none.yraw = nullptr; none.scale = none.shift = none.mean = none.invstd = nullptr; none.slope = 1.f;
+    return pers_launch(pv.pg, pv.lds, pv.grid, !p->dgrad, src, ps, psh, slope, wp, dst, stat, accumulate, bw ? *bw : none, s);
+  }
+  if (bw) return MD_ERR_UNSUPPORTED;
   int nchunks = md_cdiv(g.N16, PNREP * 16);
   const int boxes = p->N * g.nbt * g.nby * g.nbx;
   {   // few boxes (the deep, small layers): split the destination channels over more workgroups so every CU gets one
@@ -821,13 +795,25 @@ static int patch_launch_one(const PatchPlan* p, const PGeom& g, size_t lds, cons
   return MD_OK;
 }
 
+// bw != nullptr: data gradient with the fused BatchNorm-backward reduction (every launch of the plan must have the
+// persistent form: patch_can_fuse); `stat` then receives patch_blocks(p) partial rows.
+bool patch_can_fuse(const PatchPlan* p) {
+  if (!p->dgrad) return false;
+  // instantiated without register spills: up to 3 channel tiles (and then at most 4 staged items per thread with 3)
+  auto ok = [](const PersVariant& pv) { return pv.on && pv.pg.g.N16 <= 48 && !(pv.pg.g.N16 == 48 && pv.pg.nit > 4); };
+  if (!p->ncls) return ok(p->pers);
+  for (int c = 0; c < p->ncls; ++c) if (!ok(p->cls[c].pers)) return false;
+  return true;
+}
 int patch_launch(const PatchPlan* p, const float* src, const float* ps, const float* psh, float slope, const float* wp,
-                 float* dst, float* stat, int accumulate, hipStream_t s) {
-  if (!p->ncls) return patch_launch_one(p, p->g, p->lds, src, ps, psh, slope, wp, dst, stat, accumulate, s);
+                 float* dst, float* stat, int accumulate, hipStream_t s, const PersBwd* bw) {
+  if (bw && !patch_can_fuse(p)) return MD_ERR_UNSUPPORTED;
+  if (!p->ncls) return patch_launch_one(p, p->g, p->lds, p->pers, src, ps, psh, slope, wp, dst, stat, accumulate, bw, s);
   for (int c = 0; c < p->ncls; ++c) {        // residue classes write disjoint pixels of dst
-    const int rc = patch_launch_one(p, p->cls[c].g, p->cls[c].lds, src, ps, psh, slope, wp + p->cls[c].wp_off, dst, stat,
-                                    accumulate, s);
+    const int rc = patch_launch_one(p, p->cls[c].g, p->cls[c].lds, p->cls[c].pers, src, ps, psh, slope, wp + p->cls[c].wp_off, dst,
+                                    stat, accumulate, bw, s);
     if (rc) return rc;
+    if (stat) stat += (size_t)variant_blocks(p, p->cls[c].g, p->cls[c].pers) * 2 * p->cls[c].g.Cpd;
   }
   return MD_OK;
 }

@@ -1,0 +1,130 @@
+// Shared device helpers and the geometry record of the LDS-patch convolution kernels (conv_patch.hip: one box per
+// workgroup, weights streamed per stage; conv_pers.hip: persistent workgroups, weights resident in LDS).
+#pragma once
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define PM 128            // rows (output pixels) per workgroup
+#define PNREP 9           // up to 144 destination channels per workgroup
+#define PB_PITCH 160      // B tile row pitch (bytes): 8 chunks of 16 B + pad, (160/16) % 4 == 2
+#define PMAXC 320
+
+struct PGeom {
+  int Ts, Hs, Ws, Cps;      // source dims, channel pitch (floats)
+  int Td, Hd, Wd, Cpd;      // destination dims, channel pitch (floats)
+  int kh, kw, khw, taps;
+  int org_t, org_h, org_w;  // source coordinate = box origin * stride + org + patch coordinate
+  int st, sh, sw;           // stride of the (forward) convolution; 1 for the data gradient
+  int strided;              // 1: data gradient of a strided convolution (per-tap divisibility test)
+  int dst_, dsh_, dsw_;     // the convolution's stride (strided data gradient)
+  int lt, lh, lw, oddmask;  // log2 strides; packed mask of the low bits that must be zero
+  int kt, padt, padh, padw;
+  int zero_off;             // byte offset of the all-zero pixel
+  int bt, by, bx, byx;      // output box
+  int nbt, nby, nbx;        // boxes per clip
+  int pt, py, px, pyx, P;   // patch dims
+  int C8;                   // 8-channel chunks per pixel in LDS
+  int ppitch;               // LDS bytes per patch pixel (hi array); lo array follows at lo_off
+  int lo_off;
+  int Kc8;                  // taps * C8
+  int nstages;              // ceil(Kc8 / 8): 64 k per stage
+  int N16;
+  unsigned magicC8;         // floor(2^32 / C8) + 1 : exact item / C8 for item < 2^16 (0 when the divisor is 1)
+  unsigned m_pyx, m_px, m_byx, m_bx, m_khw, m_kw;   // same for the table decodes (all indices < 2^16)
+  unsigned src_bytes, dst_bytes;                      // tensor sizes for the buffer descriptors (< 2 GiB)
+  int Tdf, Hdf, Wdf;        // full destination dims; destination coordinate = box coordinate * dm + dp
+  int dmt, dmh, dmw, dpt, dph, dpw;   // (one residue class of a strided data gradient writes a strided subset)
+  int off_b, off_koffs, off_rows, off_pixg, off_scale;   // LDS byte offsets
+  int pack2, pk_shift, pk_kw; // pixel-pair reinterpretation of a <=4-channel, W-stride-2 input (see patch_build)
+};
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_f16(float a, float b) {
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
+// fp16 split: hi = fp16(x) (11 significant bits), lo = fp16(x - hi) -> 22 bits, i.e. fp32-level products with
+// three MFMAs.  fp16 subnormals are kept (HIP kernels run with float_denorm_mode_16_64 = preserve), so the
+// absolute error of hi+lo is <= max(2^-23 |x|, 2^-25); |x| must stay below 65504 (activations and weights do).
+__device__ __forceinline__ void split8_f16(const float* v, uint4& hi, uint4& lo) {
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h[i] = pk_f16(v[2 * i], v[2 * i + 1]);
+    const f16x2 hv = __builtin_bit_cast(f16x2, h[i]);
+    l[i] = pk_f16(v[2 * i] - (float)hv[0], v[2 * i + 1] - (float)hv[1]);
+  }
+  hi = make_uint4(h[0], h[1], h[2], h[3]);
+  lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+// split 8 floats into packed bf16 hi and lo (4 dwords each)
+__device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h[i] = pk_bf16(v[2 * i], v[2 * i + 1]);
+    const float h0 = __builtin_bit_cast(float, h[i] << 16), h1 = __builtin_bit_cast(float, h[i] & 0xffff0000u);
+    l[i] = pk_bf16(v[2 * i] - h0, v[2 * i + 1] - h1);
+  }
+  hi = make_uint4(h[0], h[1], h[2], h[3]);
+  lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+// x / d for 0 <= x, x * d < 2^32, with magic = floor(2^32 / d) + 1 (0 encodes d == 1)
+__device__ __forceinline__ int mdiv(int x, unsigned magic) { return magic ? (int)__umulhi((unsigned)x, magic) : x; }
+
+// Raw buffer descriptor over a whole tensor (< 2 GiB): loads at an out-of-range offset return zeros and stores there
+// are dropped, so edge handling needs no branches and no 64-bit address arithmetic.  MD_OOB = 2 GiB is out of range
+// for every tensor we accept and cannot wrap around when an instruction offset is added.
+#define MD_OOB 0x80000000u
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  // (bit_cast of the whole vector: indexing the builtin's result element-wise is miscompiled into one dword load)
+  const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+  return make_float4(f[0], f[1], f[2], f[3]);
+}
+
+template <bool F16>
+__device__ __forceinline__ f32x4 mma(uint4 a, uint4 b, f32x4 c) {
+  if (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+
+// ---- persistent form (conv_pers.hip)
+#define PERS_MAXI 8       // 32-byte patch items per thread (registers)
+struct PersGeom {
+  PGeom g;
+  int nboxes;
+  int nsteps;               // k32 steps = ceil(Kc8 / 4)
+  int bpitch;               // resident weight row pitch in bytes, (bpitch / 16) % 4 == 2
+  int off_bres;             // LDS byte offsets
+  int off_k, off_row, off_sc, off_red, off_bn;
+  int nit;                  // patch items per thread
+  int patch_bytes;          // LDS bytes of one team's patch ([pixel][hi | lo | pad])
+  int sc_stride, bn_stride; // floats between the scale | shift (| mean | invstd) rows in LDS
+  unsigned m_nbx, m_nby, m_nbt;
+};
+// fused BatchNorm-backward reduction (data gradient only); yraw == nullptr: off
+struct PersBwd {
+  const float* yraw;        // raw output of the unit whose activation this data gradient differentiates
+  const float* scale; const float* shift; const float* mean; const float* invstd;
+  float slope;
+};
+bool pers_finish(PersGeom* pg, size_t* lds_bytes, int* grid);
+// workgroups launched: each walks two box streams
+static inline int pers_blocks(const PersGeom& pg, int grid) { const int need = (pg.nboxes + 1) / 2; return grid < need ? grid : need; }
+size_t pers_bres_bytes(int Kc8, int N16);
+size_t pers_fixed_bytes(int Cps, int N16);
+int pers_launch(const PersGeom& pg, size_t lds, int grid, bool f16, const float* src, const float* ps, const float* psh, float slope,
+                const float* wp, float* dst, float* stat, int accumulate, const PersBwd& bw, hipStream_t s);

@@ -8,6 +8,7 @@
 //   * block outputs z = leaky(skip + main) are materialised (two consumers each);
 //   * backward keeps 4 gradient scratch buffers and runs BN-backward in place.
 #include <vector>
+#include <cstdlib>
 #include <new>
 #include "common.h"
 
@@ -62,6 +63,9 @@ struct MdPlan {
   bool side_used = false;     // work was queued on the side stream since the last join
   int side_state = 0;         // 0 not tried, 1 available, -1 unavailable (then everything stays on the caller's stream)
   bool defer_join = false;    // md_plan_backward_range leaves the join to the caller (md_plan_join)
+  // red_blocks[u] > 0: the data gradient of u's consumer has already left g = dA * leaky'(bn(y_u)) in the gradient buffer
+  // and that many partial rows of the BatchNorm-backward reduction in the partial buffer (md_conv_dgrad_bnred)
+  std::vector<int> red_blocks;
 };
 
 static bool side_stream(MdPlan* P) {
@@ -181,6 +185,8 @@ extern "C" int md_plan_create(int32_t B, int32_t T, int32_t H, int32_t W, const 
     size_t pf = (size_t)md_conv_fwd_stat_blocks(&u.d) * 2 * u.Cp;
     const size_t pb = (size_t)md_bn_bwd_blocks(u.rows, u.d.Cout) * 2 * u.Cp;
     if (pb > pf) pf = pb;
+    const size_t pr = (size_t)md_conv_dgrad_bnred_blocks(&u.d) * 2 * md_cpad(u.d.Cin);     // fused reduction of the producer
+    if (pr > pf) pf = pr;
     if (pf > pmax) pmax = pf;
   }
   P->part_floats = pmax;
@@ -197,6 +203,7 @@ extern "C" int md_plan_create(int32_t B, int32_t T, int32_t H, int32_t W, const 
   P->slab_off = take(smax);
   P->coef_off = take(2 * 1024);
   P->gmax = gmax;
+  P->red_blocks.assign(P->units.size(), 0);
   for (int i = 0; i < 4; ++i) P->g_off[i] = take(gmax);
   P->total_floats = off;
   *out = P;
@@ -414,10 +421,17 @@ static int unit_backward(MdPlan* P, float* ws, int ui, int gb, int dxb, int accu
   (void)w;
   if (!bn_done) {
     MdActView mainv = unit_out_view(P, ws, ui);
-    const int nb = md_bn_bwd_blocks(u.rows, u.d.Cout);
-    RC(md_bn_bwd_reduce(G, &mainv, nullptr, 1.f, st, st + u.Cp, u.rows, u.d.Cout, ws + P->part_off, stream));
-    RC(md_bn_bwd_finalize(ws + P->part_off, nb, u.d.Cout, u.rows, dgamma[ui], dbeta[ui], ws + P->coef_off, stream));
-    RC(md_bn_bwd_apply(G, &mainv, nullptr, 1.f, st, st + u.Cp, ws + P->coef_off, u.rows, u.d.Cout, G, nullptr, stream));
+    if (P->red_blocks[ui] > 0) {
+      // the consumer's data gradient already reduced: G holds g, the partial buffer its sums
+      RC(md_bn_bwd_finalize(ws + P->part_off, P->red_blocks[ui], u.d.Cout, u.rows, dgamma[ui], dbeta[ui], ws + P->coef_off, stream));
+      RC(md_bn_bwd_apply_g(G, &mainv, st, st + u.Cp, ws + P->coef_off, u.rows, u.d.Cout, G, stream));
+      P->red_blocks[ui] = 0;
+    } else {
+      const int nb = md_bn_bwd_blocks(u.rows, u.d.Cout);
+      RC(md_bn_bwd_reduce(G, &mainv, nullptr, 1.f, st, st + u.Cp, u.rows, u.d.Cout, ws + P->part_off, stream));
+      RC(md_bn_bwd_finalize(ws + P->part_off, nb, u.d.Cout, u.rows, dgamma[ui], dbeta[ui], ws + P->coef_off, stream));
+      RC(md_bn_bwd_apply(G, &mainv, nullptr, 1.f, st, st + u.Cp, ws + P->coef_off, u.rows, u.d.Cout, G, nullptr, stream));
+    }
   }
   MdActView in = unit_in_view(P, ws, ui);
   if (side_stream(P)) {
@@ -435,8 +449,22 @@ static int unit_backward(MdPlan* P, float* ws, int ui, int gb, int dxb, int accu
   }
   if (dxb >= 0) {
     RC(await_buffer(P, dxb, stream));
+    // Which unit's BatchNorm-backward consumes what this data gradient writes?  The producer of the input when the input is
+    // a raw unit output (BN-on-read), or the stem's second unit when the input is its materialised activation z[1] and this
+    // launch completes dZ1 (accumulate).  Block outputs z[k>1] close with the residual form: not fused.
+    static const int fuse_on = !(getenv("MD_FUSE_BNRED") && atoi(getenv("MD_FUSE_BNRED")) == 0);
+    const int target = u.in_unit >= 0 ? u.in_unit : ((u.in_z == 1 && accumulate) ? 1 : -1);
+    const int nbr = (fuse_on && target >= 0) ? md_conv_dgrad_bnred_blocks(&u.d) : 0;
     ProfScope ps(P, KC_DGRAD, unit_flops(u), stream);
-    RC(md_conv_dgrad(&u.d, G, ws + u.wd_off, ws + P->g_off[dxb], accumulate, stream));
+    if (nbr > 0) {
+      const Unit& tu = P->units[target];
+      MdActView tv = unit_out_view(P, ws, target);
+      float* tst = ws + tu.stat_off;
+      RC(md_conv_dgrad_bnred(&u.d, G, ws + u.wd_off, ws + P->g_off[dxb], accumulate, &tv, tst, tst + tu.Cp, ws + P->part_off, stream));
+      P->red_blocks[target] = nbr;
+    } else {
+      RC(md_conv_dgrad(&u.d, G, ws + u.wd_off, ws + P->g_off[dxb], accumulate, stream));
+    }
   }
   return MD_OK;
 }
@@ -483,6 +511,7 @@ extern "C" int md_plan_backward_range(MdPlan* P, const float* dfeat, const float
   if (stage_hi == 4) {
     if (!dfeat) return MD_ERR_NULL;
     P->bwd_p = 0;
+    for (int& r : P->red_blocks) r = 0;
     const ZT& zl = P->z.back();
     RC(await_buffer(P, 0, stream));
     RC(md_avgpool_bwd(dfeat, P->B, zl.C, zl.rows / P->B, ws + P->g_off[0], stream));

@@ -38,6 +38,7 @@ SIGNATURES = {
     "md_version": (C.c_int, [C.POINTER(C.c_char_p)]),
     "md_set_exact_fp32": (C.c_int, [C.c_int]),
     "md_get_exact_fp32": (C.c_int, []),
+    "md_set_pers_grid": (C.c_int, [C.c_int]),
     "md_conv_wpack_fwd_floats": (_SZ, [_DESC]),
     "md_conv_wpack_dgrad_floats": (_SZ, [_DESC]),
     "md_conv_pack_weights": (C.c_int, [_DESC, _P, _P, _P, _P]),
@@ -54,6 +55,9 @@ SIGNATURES = {
     "md_bn_bwd_reduce": (C.c_int, [_P, _VIEW, _VIEW, _F, _P, _P, _I64, _I32, _P, _P]),
     "md_bn_bwd_finalize": (C.c_int, [_P, _I32, _I32, _I64, _P, _P, _P, _P]),
     "md_bn_bwd_apply": (C.c_int, [_P, _VIEW, _VIEW, _F, _P, _P, _P, _I64, _I32, _P, _P, _P]),
+    "md_conv_dgrad_bnred_blocks": (_I32, [_DESC]),
+    "md_conv_dgrad_bnred": (C.c_int, [_DESC, _P, _P, _P, C.c_int, _VIEW, _P, _P, _P, _P]),
+    "md_bn_bwd_apply_g": (C.c_int, [_P, _VIEW, _P, _P, _P, _I64, _I32, _P, _P]),
     "md_nchw_to_cl": (C.c_int, [_P, _I32, _I32, _I64, _P, _P]),
     "md_cl_to_nchw": (C.c_int, [_P, _I32, _I32, _I64, _P, _P]),
     "md_avgpool_fwd": (C.c_int, [_P, _I32, _I32, _I64, _P, _P]),

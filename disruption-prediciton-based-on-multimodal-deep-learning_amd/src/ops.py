@@ -114,6 +114,41 @@ def conv_dgrad(d: N.MdConvDesc, dy: torch.Tensor, wd: torch.Tensor, out: Optiona
     return out
 
 
+def conv_dgrad_bnred(d: N.MdConvDesc, dy: torch.Tensor, wd: torch.Tensor, y_view: N.MdActView, st: torch.Tensor,
+                     out: Optional[torch.Tensor] = None, accumulate: bool = False):
+    """Data gradient with the BatchNorm-backward reduction of the producing unit fused into the epilogue
+    (md_conv_dgrad_bnred): returns (g, partial) or None when this geometry has no fused form.  ``y_view`` is the
+    producer's raw output with its BatchNorm scale/shift/slope, ``st`` its [mean, invstd, scale, shift] rows."""
+    require_cuda(dy, wd, out, st)
+    L = N.lib()
+    nb = L.md_conv_dgrad_bnred_blocks(C.byref(d))
+    if nb <= 0:
+        return None
+    if out is None:
+        out = torch.empty((d.N, d.Ti, d.Hi, d.Wi, cpad(d.Cin)), device=dy.device, dtype=torch.float32)
+        accumulate = False
+    part = torch.empty((nb, 2, cpad(d.Cin)), device=dy.device, dtype=torch.float32)
+    N.check(L.md_conv_dgrad_bnred(C.byref(d), _p(dy), _p(wd), _p(out), int(accumulate), C.byref(y_view), _p(st[0]), _p(st[1]),
+                                  _p(part), _stream()), "md_conv_dgrad_bnred")
+    return out, part
+
+
+def bn_backward_from_g(g: torch.Tensor, part: torch.Tensor, main: N.MdActView, st: torch.Tensor, Cc: int):
+    """Finalize + apply after a fused reduction: returns (d_raw, dgamma, dbeta)."""
+    require_cuda(g, part, st)
+    L = N.lib()
+    rows = g.numel() // g.shape[-1]
+    Cp = cpad(Cc)
+    dgamma = torch.empty(Cc, device=g.device, dtype=torch.float32)
+    dbeta = torch.empty(Cc, device=g.device, dtype=torch.float32)
+    coef = torch.empty((2, Cp), device=g.device, dtype=torch.float32)
+    N.check(L.md_bn_bwd_finalize(_p(part), part.shape[0], Cc, rows, _p(dgamma), _p(dbeta), _p(coef), _stream()), "md_bn_bwd_finalize")
+    d_raw = torch.empty_like(g)
+    N.check(L.md_bn_bwd_apply_g(_p(g), C.byref(main), _p(st[0]), _p(st[1]), _p(coef), rows, Cc, _p(d_raw), _stream()),
+            "md_bn_bwd_apply_g")
+    return d_raw, dgamma, dbeta
+
+
 def conv_wgrad(d: N.MdConvDesc, x: N.MdActView, dy: torch.Tensor) -> torch.Tensor:
     require_cuda(dy)
     dw = torch.empty((d.Cout, d.Cin, d.kt, d.kh, d.kw), device=dy.device, dtype=torch.float32)

@@ -43,6 +43,10 @@ int md_version(const char** arch_out);
  * Packed weights depend on the mode: change it only between steps.  Returns the previous mode. */
 int md_set_exact_fp32(int on);
 int md_get_exact_fp32(void);
+/* Test knob: n > 0 forces the persistent convolution kernels (weights resident in LDS, one workgroup walking many
+ * boxes) to a grid of n workgroups, also on shapes too small to qualify by themselves; 0 restores the default
+ * (one workgroup per CU, only where there are at least as many boxes).  Returns the previous value. */
+int md_set_pers_grid(int n);
 
 /* ------------------------------------------------------------------------------------------------
  * Convolution as implicit GEMM on the matrix cores (replaces nn.Conv3d fwd/bwd as used by
@@ -138,6 +142,18 @@ int md_bn_bwd_finalize(const float* partial, int32_t blocks, int32_t C, int64_t 
 int md_bn_bwd_apply(const float* dA, const MdActView* main, const MdActView* skip, float alpha,
                     const float* mean, const float* invstd, const float* coef, int64_t rows, int32_t C,
                     float* d_raw, float* dS, void* stream);
+
+/* Fused form of (1) for the units that feed a convolution directly: the data gradient of the CONSUMER convolution
+ * writes g = dA * leaky'(bn(y)) (y = `y_view`, the raw output + BatchNorm constants of the unit being differentiated)
+ * instead of dA and leaves the partial sums of (1) in `partial`
+ * ([md_conv_dgrad_bnred_blocks(d)][2][md_cpad(Cin)]), so no separate reduction pass reads the tensor again.
+ * md_conv_dgrad_bnred_blocks returns 0 when this geometry has no fused form (use md_conv_dgrad + md_bn_bwd_reduce).
+ * (3) then runs as md_bn_bwd_apply_g, which takes g instead of dA.  Backward of Conv3dBlock, R2Plus1D.py:53-58. */
+int32_t md_conv_dgrad_bnred_blocks(const MdConvDesc* d);
+int md_conv_dgrad_bnred(const MdConvDesc* d, const float* dy_raw, const float* wpack_dgrad, float* g_out, int accumulate,
+                        const MdActView* y_view, const float* mean, const float* invstd, float* partial, void* stream);
+int md_bn_bwd_apply_g(const float* g, const MdActView* main, const float* mean, const float* invstd, const float* coef,
+                      int64_t rows, int32_t C, float* d_raw, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Boundary layout conversion, pooling, classifier head, losses.

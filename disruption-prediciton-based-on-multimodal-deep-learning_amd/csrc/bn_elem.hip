@@ -4,6 +4,7 @@
 // 16-byte channel chunk (so per-channel constants are loaded once) and walks rows; consecutive threads
 // touch consecutive 16-byte chunks, i.e. fully coalesced 1 KiB wave accesses.
 #include "common.h"
+#include "patch_common.h"
 
 struct View {
   const float* p; const float* scale; const float* shift; float slope;
@@ -34,6 +35,13 @@ __device__ __forceinline__ float4 dact_of(const View& v, float4 pre) {
 }
 __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// d_raw of one element from g, the raw conv output and the per-channel constants; ONE definition for the fp32 and the
+// pre-split apply kernels so that both evaluate it with the same operations (their outputs must agree bit for bit).
+__device__ __forceinline__ float md_bn_apply1(float gq, float raw, float mu, float is, float sc, float c1, float c2) {
+  const float xh = __fmul_rn(__fsub_rn(raw, mu), is);
+  return __fmul_rn(sc, __fsub_rn(__fsub_rn(gq, c1), __fmul_rn(xh, c2)));
+}
 
 // Row walk shared by the streaming kernels: thread -> (chunk c4, row lane r); block -> row range.
 struct RowWalk { int c4, r, nr; int64_t beg, end; bool active; };
@@ -189,10 +197,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd(const float* __restrict__ dA, Vi
       const float4 xh = make_float4((raw.x - mu.x) * is.x, (raw.y - mu.y) * is.y, (raw.z - mu.z) * is.z, (raw.w - mu.w) * is.w);
       if (APPLY) {
         float4 r;
-        r.x = km.sc.x * (gq.x - c1.x - xh.x * c2.x);
-        r.y = km.sc.y * (gq.y - c1.y - xh.y * c2.y);
-        r.z = km.sc.z * (gq.z - c1.z - xh.z * c2.z);
-        r.w = km.sc.w * (gq.w - c1.w - xh.w * c2.w);
+        r.x = md_bn_apply1(gq.x, raw.x, mu.x, is.x, km.sc.x, c1.x, c2.x);
+        r.y = md_bn_apply1(gq.y, raw.y, mu.y, is.y, km.sc.y, c1.y, c2.y);
+        r.z = md_bn_apply1(gq.z, raw.z, mu.z, is.z, km.sc.z, c1.z, c2.z);
+        r.w = md_bn_apply1(gq.w, raw.w, mu.w, is.w, km.sc.w, c1.w, c2.w);
         *(float4*)(d_raw + o) = r;
       } else {
         a1 = add4(a1, gq);
@@ -238,6 +246,66 @@ __global__ __launch_bounds__(256) void k_bn_bwd(const float* __restrict__ dA, Vi
       *(float4*)(sp + Cp + w.c4 * 4) = s;
     }
   }
+}
+
+// Apply pass writing d_raw in the pre-split bf16 format the data-gradient / weight-gradient kernels stage without any
+// arithmetic: [row][C8 chunks]{hi 8 x bf16 | lo 8 x bf16}, 32 bytes per 8 channels (same bytes as fp32, Cp % 8 == 0, so
+// the pass may run in place).  A thread owns one 8-channel chunk (per-channel constants loaded once) and walks rows.
+// The hi/lo split is exactly the kernels' own split8(), so results are bit-identical to staging the fp32 tensor.
+template <bool GIN>
+__global__ __launch_bounds__(256) void k_bn_bwd_apply_split(const float* __restrict__ dA, View main, View skip, int has_skip,
+                                                            float alpha, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, const float* __restrict__ coef,
+                                                            int64_t rows, int C8, uint4* __restrict__ d_split,
+                                                            float* __restrict__ dS) {
+  const int nr = blockDim.x / C8, c8 = threadIdx.x % C8, r0 = threadIdx.x / C8;
+  if (r0 >= nr) return;
+  const int Cp = C8 * 8;
+  const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+  const int64_t beg = (int64_t)blockIdx.x * per, end = beg + per < rows ? beg + per : rows;
+  float sc[8], sh[8], mu[8], is[8], c1[8], c2[8], ssc[8], ssh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = c8 * 8 + e;
+    sc[e] = main.scale[c]; sh[e] = main.shift[c]; mu[e] = mean[c]; is[e] = invstd[c]; c1[e] = coef[c]; c2[e] = coef[Cp + c];
+    ssc[e] = (has_skip && skip.scale) ? skip.scale[c] : 1.f; ssh[e] = (has_skip && skip.scale) ? skip.shift[c] : 0.f;
+  }
+  auto one = [&](int64_t row) {
+    const size_t o = ((size_t)row * C8 + c8) * 8;
+    const float4 ra = *(const float4*)(main.p + o), rb = *(const float4*)(main.p + o + 4);
+    const float4 da = *(const float4*)(dA + o), db = *(const float4*)(dA + o + 4);
+    float raw[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+    float d[8] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};
+    if (has_skip) {
+      const float4 sa = *(const float4*)(skip.p + o), sb = *(const float4*)(skip.p + o + 4);
+      const float sk[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float sv = skip.scale ? md_leaky(fmaf(sk[e], ssc[e], ssh[e]), skip.slope) : sk[e];
+        const float sum = sv + md_leaky(fmaf(raw[e], sc[e], sh[e]), main.slope);
+        d[e] *= md_dleaky(sum, alpha);
+      }
+      *(float4*)(dS + o) = make_float4(d[0], d[1], d[2], d[3]);
+      *(float4*)(dS + o + 4) = make_float4(d[4], d[5], d[6], d[7]);
+    }
+    float r[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float pre = fmaf(raw[e], sc[e], sh[e]);
+      const float gq = GIN ? d[e] : __fmul_rn(d[e], md_dleaky(pre, main.slope));
+      r[e] = md_bn_apply1(gq, raw[e], mu[e], is[e], sc[e], c1[e], c2[e]);
+      // the split below must see the ROUNDED fp32 value, as a consumer staging the fp32 tensor would: without this the
+      // compiler contracts the final multiply into the (x - hi) subtraction of split8 and lo comes out different
+      asm volatile("" : "+v"(r[e]));
+    }
+    uint4 hi, lo;
+    split8(r, hi, lo);
+    d_split[((size_t)row * C8 + c8) * 2] = hi;
+    d_split[((size_t)row * C8 + c8) * 2 + 1] = lo;
+  };
+  int64_t row = beg + r0;
+  for (; row + (int64_t)nr < end; row += 2 * (int64_t)nr) { one(row); one(row + nr); }
+  for (; row < end; row += nr) one(row);
 }
 
 __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict__ partial, int blocks, int C, int Cp,
@@ -401,6 +469,43 @@ extern "C" int md_bn_bwd_apply(const float* dA, const MdActView* main, const MdA
   MD_KLAUNCH(k_bn_bwd<true>, dim3(stream_blocks(rows, C4)), dim3(256), 0, (hipStream_t)stream, dA, to_view(main),
                      to_view(skip), skip != nullptr ? 1 : 0, alpha, mean, invstd, coef, rows, C4, (float*)nullptr,
                      d_raw, dS);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+// General form of the apply pass (md_bn_bwd_apply / md_bn_bwd_apply_g are the fp32-output special cases): g_in != 0 means
+// dA already holds g; split_out != 0 writes d_raw in the pre-split bf16 format (needs md_cpad(C) % 8 == 0).
+extern "C" int md_bn_bwd_apply_fmt(const float* dA, int g_in, const MdActView* main, const MdActView* skip, float alpha,
+                                   const float* mean, const float* invstd, const float* coef, int64_t rows, int32_t C,
+                                   void* d_raw, int split_out, float* dS, void* stream) {
+  if (!dA || !main || !main->data || !mean || !invstd || !coef || !d_raw) return MD_ERR_NULL;
+  if (skip != nullptr && !dS) return MD_ERR_NULL;
+  if (g_in && skip != nullptr) return MD_ERR_UNSUPPORTED;
+  int rc = check_rows(rows, C); if (rc) return rc;
+  const int Cp = md_cpad(C), C4 = Cp / 4;
+  if (!split_out) {
+    if (g_in) {
+      if (!main->scale) return MD_ERR_NULL;
+      MD_KLAUNCH((k_bn_bwd<true, true>), dim3(stream_blocks(rows, C4)), dim3(256), 0, (hipStream_t)stream, dA, to_view(main),
+                 to_view(nullptr), 0, 1.f, mean, invstd, coef, rows, C4, (float*)nullptr, (float*)d_raw, (float*)nullptr);
+    } else {
+      MD_KLAUNCH(k_bn_bwd<true>, dim3(stream_blocks(rows, C4)), dim3(256), 0, (hipStream_t)stream, dA, to_view(main),
+                 to_view(skip), skip != nullptr ? 1 : 0, alpha, mean, invstd, coef, rows, C4, (float*)nullptr, (float*)d_raw, dS);
+    }
+    MD_CHECK_LAUNCH();
+    return MD_OK;
+  }
+  if ((Cp & 7) || !main->scale || !main->shift) return MD_ERR_UNSUPPORTED;
+  const int C8 = Cp / 8;
+  if (C8 > 256) return MD_ERR_UNSUPPORTED;
+  const int nr = 256 / C8;
+  int64_t blocks = md_cdiv64(rows, (int64_t)nr * 8);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 4096) blocks = 4096;
+  if (g_in) MD_KLAUNCH((k_bn_bwd_apply_split<true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dA, to_view(main),
+                       to_view(nullptr), 0, 1.f, mean, invstd, coef, rows, C8, (uint4*)d_raw, (float*)nullptr);
+  else MD_KLAUNCH((k_bn_bwd_apply_split<false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dA, to_view(main),
+                  to_view(skip), skip != nullptr ? 1 : 0, alpha, mean, invstd, coef, rows, C8, (uint4*)d_raw, dS);
   MD_CHECK_LAUNCH();
   return MD_OK;
 }

@@ -72,6 +72,6 @@ struct WgradPlan;
 const WgradPlan* wgrad_lookup(const MdConvDesc* d);
 size_t wgrad_patch_workspace_floats(const WgradPlan* p);
 int wgrad_patch_launch(const WgradPlan* p, const MdConvDesc* d, const float* src, const float* ps, const float* psh,
-                       float slope, const float* dy, float* dw, float* slab, hipStream_t s);
+                       float slope, const float* dy, float* dw, float* slab, hipStream_t s, int ysplit = 0);
 int patch_pack_batch(int n, const MdConvDesc* const* descs, const int* dgrad, const float* const* w, float* const* outs,
                      unsigned char* handled, hipStream_t s);

@@ -10,6 +10,7 @@
 // (ds_read_b128) and feeds its 4 floats to 4 consecutive MFMAs; lane group g therefore supplies
 // k = 16*s + 4*g + e to MFMA e, identically for A and B, which is a permutation of the K axis and
 // leaves the product unchanged.  LDS row pitch 40 floats makes those b128 reads bank-conflict free.
+#include <cstdlib>
 #include "common.h"
 #include "patch_common.h"
 
@@ -528,6 +529,50 @@ extern "C" int md_conv_dgrad_bnred(const MdConvDesc* d, const float* dy_raw, con
   PersBwd bw; bw.yraw = y_view->data; bw.scale = y_view->scale; bw.shift = y_view->shift; bw.mean = mean; bw.invstd = invstd;
   bw.slope = y_view->slope;
   return patch_launch(pp, dy_raw, nullptr, nullptr, 1.f, wpack_dgrad, g_out, partial, accumulate, (hipStream_t)stream, &bw);
+}
+
+// ---- gradients in the pre-split bf16 format (written by md_bn_bwd_apply_fmt with split_out): accepted when every kernel
+// that reads this unit's d_raw is a patch kernel and the channel pitch is a whole number of 8-channel chunks
+extern "C" int md_conv_split_dy_ok(const MdConvDesc* d, int need_dgrad) {
+  if (check_desc(d) != MD_OK) return 0;
+  if (md_cpad(d->Cout) & 7) return 0;
+  // Measured on the BASELINE step (profiles/r02k_*): the consumers gain 2-3 % (their staging is not what bounds them)
+  // while the split-writing apply pass is 0.3 ms slower than the fp32 one, so the executor keeps fp32 gradients unless
+  // MD_SPLIT_DY=1; the format stays available (and bit-exactly tested) for callers that re-read a gradient many times.
+  static const int on = getenv("MD_SPLIT_DY") && atoi(getenv("MD_SPLIT_DY")) == 1;
+  if (!on) return 0;
+  if (!wgrad_lookup(d)) return 0;
+  if (need_dgrad && !patch_lookup(d, 1)) return 0;
+  return 1;
+}
+extern "C" int md_conv_dgrad_fmt(const MdConvDesc* d, const void* dy, int dy_split, const float* wpack_dgrad, float* dx,
+                                 int accumulate, const MdActView* y_view, const float* mean, const float* invstd,
+                                 float* partial, void* stream) {
+  int rc = check_desc(d);
+  if (rc != MD_OK) return rc;
+  if (!dy || !wpack_dgrad || !dx) return MD_ERR_NULL;
+  if (!dy_split && !y_view) return md_conv_dgrad(d, (const float*)dy, wpack_dgrad, dx, accumulate, stream);
+  if (!dy_split) return md_conv_dgrad_bnred(d, (const float*)dy, wpack_dgrad, dx, accumulate, y_view, mean, invstd, partial, stream);
+  const PatchPlan* pp = patch_lookup(d, 1);
+  if (!pp || (md_cpad(d->Cout) & 7)) return MD_ERR_UNSUPPORTED;
+  const int acc = (accumulate ? 1 : 0) | 0x10000;
+  if (!y_view) return patch_launch(pp, (const float*)dy, nullptr, nullptr, 1.f, wpack_dgrad, dx, nullptr, acc, (hipStream_t)stream);
+  if (!y_view->data || !y_view->scale || !y_view->shift || !mean || !invstd || !partial) return MD_ERR_NULL;
+  if (!patch_can_fuse(pp)) return MD_ERR_UNSUPPORTED;
+  PersBwd bw; bw.yraw = y_view->data; bw.scale = y_view->scale; bw.shift = y_view->shift; bw.mean = mean; bw.invstd = invstd;
+  bw.slope = y_view->slope;
+  return patch_launch(pp, (const float*)dy, nullptr, nullptr, 1.f, wpack_dgrad, dx, partial, acc, (hipStream_t)stream, &bw);
+}
+extern "C" int md_conv_wgrad_fmt(const MdConvDesc* d, const MdActView* x, const void* dy, int dy_split, float* dw,
+                                 float* workspace, void* stream) {
+  if (!dy_split) return md_conv_wgrad(d, x, (const float*)dy, dw, workspace, stream);
+  int rc = check_desc(d);
+  if (rc != MD_OK) return rc;
+  if (!x || !x->data || !dy || !dw) return MD_ERR_NULL;
+  const WgradPlan* wp = wgrad_lookup(d);
+  if (!wp || (md_cpad(d->Cout) & 7)) return MD_ERR_UNSUPPORTED;
+  if (!workspace) return MD_ERR_WORKSPACE;
+  return wgrad_patch_launch(wp, d, x->data, x->scale, x->shift, x->slope, (const float*)dy, dw, workspace, (hipStream_t)stream, 1);
 }
 
 extern "C" size_t md_conv_wgrad_workspace_floats(const MdConvDesc* d) {

@@ -29,7 +29,9 @@ template <bool F16, int NT = 256>
 __device__ __forceinline__ void stage_image(__amdgpu_buffer_rsrc_t src, int Cpitch, int c0, int cvalid4,
                                             const int* sG, int npix, int C8, unsigned magic, char* img, int pitch,
                                             int lo_off, bool prologue, const float* sScale, const float* sShift,
-                                            float pslope, int t) {
+                                            float pslope, int t, bool presplit = false) {
+  // presplit: the source is a gradient tensor already stored as bf16 hi|lo pairs, [pixel][C8 chunks]{hi 8 x bf16, lo 8 x bf16}
+  // (32 bytes per 8 channels, written by md_bn_bwd_apply_fmt): staging is a plain copy, no VALU arithmetic at all.
   const int total = npix * C8;
   for (int base = 0; base < total; base += NT * 4) {
     float4 va[4], vb[4];
@@ -41,9 +43,9 @@ __device__ __forceinline__ void stage_image(__amdgpu_buffer_rsrc_t src, int Cpit
       const int c8 = item - pixel * C8;
       const int gp = sG[pixel];
       const bool in = gp >= 0 && c8 * 2 < cvalid4;
-      const unsigned off = in ? (unsigned)(gp * Cpitch + c0 + c8 * 8) * 4u : MD_OOB;
+      const unsigned off = in ? (presplit ? (unsigned)(gp * C8 + c8) * 32u : (unsigned)(gp * Cpitch + c0 + c8 * 8) * 4u) : MD_OOB;
       va[u] = buf_load4(src, off);
-      vb[u] = buf_load4(src, (in && c8 * 2 + 1 < cvalid4) ? off + 16u : MD_OOB);
+      vb[u] = buf_load4(src, (in && (presplit || c8 * 2 + 1 < cvalid4)) ? off + 16u : MD_OOB);
       pix[u] = base + u * NT + t < total ? (pixel | (in ? 0 : 0x20000000)) : -1;
       c8s[u] = c8;
     }
@@ -65,7 +67,8 @@ __device__ __forceinline__ void stage_image(__amdgpu_buffer_rsrc_t src, int Cpit
         }
       }
       uint4 hi, lo;
-      if (F16) split8_f16(v, hi, lo); else split8(v, hi, lo);
+      if (presplit) { hi = __builtin_bit_cast(uint4, va[u]); lo = __builtin_bit_cast(uint4, vb[u]); }
+      else if (F16) split8_f16(v, hi, lo); else split8(v, hi, lo);
       char* d = img + pixel * pitch + c8s[u] * 16;
       *(uint4*)d = hi;
       *(uint4*)(d + lo_off) = lo;
@@ -102,6 +105,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void k_conv_patch(
   const int ncols = min(n_per_blk, g.N16 - n0);
   const bool prologue = pscale != nullptr;
   const int dbg = (accumulate >> 8) & 0xff;      // timing experiments (MD_DBG): 1 skip patch loads, 2 skip MFMA loop, 4 skip stores
+  const bool presplit = (accumulate >> 16) & 1;   // source = pre-split bf16 gradient (data gradient only)
   accumulate &= 1;
 
   // ---- which box
@@ -181,8 +185,9 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void k_conv_patch(
 
   // ---- stage the patch: global 32 B per lane -> (BN+act) -> split -> 16 B hi + 16 B lo
   if (!(dbg & 1))
-    stage_image<F16, NT>(make_rsrc(src, g.src_bytes), g.Cps, 0, g.Cps >> 2, sG, g.P, g.C8, g.magicC8, sP, g.ppitch, g.lo_off, prologue, sScale,
-                     sShift, pslope, t);
+    stage_image<F16, NT>(make_rsrc(src, presplit ? (unsigned)(g.src_bytes / (g.Cps * 4u)) * (unsigned)g.C8 * 32u : g.src_bytes), g.Cps, 0,
+                         presplit ? 2 * g.C8 : g.Cps >> 2, sG, g.P, g.C8, g.magicC8, sP, g.ppitch, g.lo_off, prologue, sScale, sShift, pslope, t,
+                         presplit);
   if (STRIDED) {
     for (int i = t * 16; i < g.ppitch; i += NT * 16) {
       *(uint4*)(sP + g.zero_off + i) = make_uint4(0, 0, 0, 0);
@@ -739,6 +744,8 @@ int patch_pack(const MdConvDesc* d, int dgrad, const PatchPlan* p, const float* 
 static int patch_launch_one(const PatchPlan* p, const PGeom& g, size_t lds, const PersVariant& pv, const float* src, const float* ps,
                             const float* psh, float slope, const float* wp, float* dst, float* stat, int accumulate,
                             const PersBwd* bw, hipStream_t s) {
+  // accumulate: bit 0 = add into dst, bit 16 = src is a pre-split bf16 gradient (data gradient, pack2 excluded)
+  if ((accumulate >> 16) & 1) { if (!p->dgrad || g.pack2) return MD_ERR_UNSUPPORTED; }
   if (pv.on) {
     PersBwd none; none.yraw = nullptr; none.scale = none.shift = none.mean = none.invstd = nullptr; none.slope = 1.f;
     return pers_launch(pv.pg, pv.lds, pv.grid, !p->dgrad, src, ps, psh, slope, wp, dst, stat, accumulate, bw ? *bw : none, s);
@@ -759,7 +766,7 @@ static int patch_launch_one(const PatchPlan* p, const PGeom& g, size_t lds, cons
     if (padkb && lds + (size_t)padkb * 1024 <= 160 * 1024) lds += (size_t)padkb * 1024; else if (padkb) lds = 160 * 1024;
   }
   static const int dbg = getenv("MD_DBG") ? atoi(getenv("MD_DBG")) : 0;
-  accumulate = (accumulate & 1) | ((dbg & 0xff) << 8);
+  accumulate = (accumulate & 0x10001) | ((dbg & 0xff) << 8);
   const int nrep = npb / 16;
   // eight waves on the box when LDS leaves room for one workgroup per CU only (then nothing else would overlap)
   static const int w8_env = getenv("MD_PATCH_W8") ? atoi(getenv("MD_PATCH_W8")) : 1;
@@ -828,7 +835,9 @@ template <bool F16>
 __device__ __forceinline__ void stage_image_ptr(const float* __restrict__ src, int Cpitch, int c0, int cvalid4,
                                             const int* sG, int npix, int C8, unsigned magic, char* img, int pitch,
                                             int lo_off, bool prologue, const float* sScale, const float* sShift,
-                                            float pslope, int t) {
+                                            float pslope, int t, int presplit_c8 = 0) {
+  // presplit_c8 > 0: src is a pre-split bf16 gradient with that many 32-byte chunks per pixel ([pixel][chunk]{hi | lo});
+  // c0 (a multiple of 8) selects the first chunk; staging is then a plain copy.
   const int total = npix * C8;
   for (int base = 0; base < total; base += 256 * 4) {
     float4 va[4], vb[4];
@@ -844,10 +853,10 @@ __device__ __forceinline__ void stage_image_ptr(const float* __restrict__ src, i
         pix[u] = pixel | 0x20000000; c8s[u] = c8;        // 0x2..: nothing loaded (stays zero, no prologue)
         const int gp = sG[pixel];
         if (gp >= 0 && c8 * 2 < cvalid4) {
-          const float* s = src + (size_t)gp * Cpitch + c0 + c8 * 8;
+          const float* s = presplit_c8 ? src + ((size_t)gp * presplit_c8 + (c0 >> 3) + c8) * 8 : src + (size_t)gp * Cpitch + c0 + c8 * 8;
           va[u] = *(const float4*)s;
           pix[u] = pixel;
-          if (c8 * 2 + 1 < cvalid4) vb[u] = *(const float4*)(s + 4);
+          if (presplit_c8 || c8 * 2 + 1 < cvalid4) vb[u] = *(const float4*)(s + 4);
           else pix[u] |= 0x40000000;                       // upper half of the chunk is channel padding
         }
       }
@@ -866,7 +875,8 @@ __device__ __forceinline__ void stage_image_ptr(const float* __restrict__ src, i
         if (half) { v[4] = v[5] = v[6] = v[7] = 0.f; }
       }
       uint4 hi, lo;
-      if (F16) split8_f16(v, hi, lo); else split8(v, hi, lo);
+      if (presplit_c8) { hi = __builtin_bit_cast(uint4, va[u]); lo = __builtin_bit_cast(uint4, vb[u]); }
+      else if (F16) split8_f16(v, hi, lo); else split8(v, hi, lo);
       char* d = img + pixel * pitch + c8s[u] * 16;
       *(uint4*)d = hi;
       *(uint4*)(d + lo_off) = lo;
@@ -923,6 +933,8 @@ template <int KTW, int NREP>
 __global__ __launch_bounds__(256) void k_wgrad_patch(
     WGeom g, const float* __restrict__ src, const float* __restrict__ pscale, const float* __restrict__ pshift,
     float pslope, const float* __restrict__ dy, float* __restrict__ slab, int dbg) {
+  const int ysplit = (dbg >> 16) & 1;            // dY is a pre-split bf16 gradient ([pixel][Cpo/8 chunks]{hi | lo})
+  dbg &= 0xffff;
   extern __shared__ __attribute__((aligned(16))) char sm[];
   char* sP = sm;
   char* sY = sm + g.off_y;
@@ -994,7 +1006,8 @@ __global__ __launch_bounds__(256) void k_wgrad_patch(
     __syncthreads();
     if (!(dbg & 1)) stage_image_ptr<false>(src, g.Cpi, 0, g.Cpi >> 2, sG, g.P, g.C8i, g.magicC8, sP, g.ppitch, g.lo_off, prologue, sScale, sShift,
                 pslope, t);
-    if (!(dbg & 2)) stage_image_ptr<false>(dy, g.Cpo, n0, ycv4, sGY, PM, g.NC, g.magicNC, sY, g.ypitch, g.ylo_off, false, nullptr, nullptr, 1.f, t);
+    if (!(dbg & 2)) stage_image_ptr<false>(dy, g.Cpo, n0, ycv4, sGY, PM, g.NC, g.magicNC, sY, g.ypitch, g.ylo_off, false, nullptr, nullptr, 1.f, t,
+                                           ysplit ? (g.Cpo >> 3) : 0);
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < ((dbg & 4) ? 0 : 4); ++s) {
@@ -1058,7 +1071,8 @@ __global__ __launch_bounds__(256) void k_wgrad_patch(
 template <int KTW, int NREP, bool W8 = false>
 __global__ __launch_bounds__(W8 ? 512 : 256) void k_wgrad_patch_pf(
     WGeom g, const float* __restrict__ src, const float* __restrict__ pscale, const float* __restrict__ pshift,
-    float pslope, const float* __restrict__ dy, float* __restrict__ slab) {
+    float pslope, const float* __restrict__ dy, float* __restrict__ slab, int ysplit) {
+  // ysplit: dY is a pre-split bf16 gradient ([pixel][Cpo/8 chunks]{hi 8 x bf16 | lo 8 x bf16}): its commit is a plain copy
   extern __shared__ __attribute__((aligned(16))) char sm[];
   char* sP = sm;
   char* sY = sm + g.off_y;
@@ -1137,7 +1151,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void k_wgrad_patch_pf(
       const int rt = row / g.byx; const int r = row - rt * g.byx;
       const int ry = r / g.bx; const int rx = r - ry * g.bx;
       yloc[u] = rt | (ry << 6) | (rx << 15) | (c << 24);
-      yrel[u] = ((rt * g.Ho + ry) * g.Wo + rx) * g.Cpo + n0 + c * 8;
+      yrel[u] = ((rt * g.Ho + ry) * g.Wo + rx) * g.Cpo + n0 + c * 8;      // (same element offset in both formats: 32 B per 8 channels)
       ydst[u] = (rt < g.bt) ? row * g.ypitch + c * 16 : -2;      // -2: row outside the box -> zeros
     }
   }
@@ -1177,7 +1191,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void k_wgrad_patch_pf(
     const bool in = q_live && ydst[u] >= 0 && ot_ < g.To && oy_ < g.Ho && ox_ < g.Wo && c * 2 < ycv4;
     const unsigned off = (unsigned)(q_ybase + yrel[u]) * 4u;
     ya_[u] = buf_load4(yrs, in ? off : MD_OOB);
-    yb_[u] = buf_load4(yrs, (in && c * 2 + 1 < ycv4) ? off + 16u : MD_OOB);
+    yb_[u] = buf_load4(yrs, (in && (ysplit || c * 2 + 1 < ycv4)) ? off + 16u : MD_OOB);
   };
   auto commit = [&]() {
 #pragma unroll
@@ -1205,7 +1219,8 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void k_wgrad_patch_pf(
         const int off = row * g.ypitch + ((yloc[u] >> 24) & 255) * 16;
         const float v[8] = {ya_[u].x, ya_[u].y, ya_[u].z, ya_[u].w, yb_[u].x, yb_[u].y, yb_[u].z, yb_[u].w};
         uint4 hi, lo;
-        split8(v, hi, lo);
+        if (ysplit) { hi = __builtin_bit_cast(uint4, ya_[u]); lo = __builtin_bit_cast(uint4, yb_[u]); }
+        else split8(v, hi, lo);
         *(uint4*)(sY + off) = hi;
         *(uint4*)(sY + g.ylo_off + off) = lo;
       }
@@ -1490,9 +1505,11 @@ const WgradPlan* wgrad_lookup(const MdConvDesc* d) {
 size_t wgrad_patch_workspace_floats(const WgradPlan* p) { return (size_t)p->nslices * p->g.nkt * 16 * p->g.N16; }
 
 int wgrad_patch_launch(const WgradPlan* p, const MdConvDesc* d, const float* src, const float* ps, const float* psh,
-                       float slope, const float* dy, float* dw, float* slab, hipStream_t s) {
+                       float slope, const float* dy, float* dw, float* slab, hipStream_t s, int ysplit) {
   const WGeom& g = p->g;
-  static const int dbg = getenv("MD_DBG") ? atoi(getenv("MD_DBG")) : 0;
+  if (ysplit && (g.Cpo & 7)) return MD_ERR_UNSUPPORTED;
+  static const int dbg_env = getenv("MD_DBG") ? atoi(getenv("MD_DBG")) : 0;
+  const int dbg = (dbg_env & 0xffff) | (ysplit ? 0x10000 : 0);
   dim3 grid(p->nslices, g.nkg * g.nng);
   const bool pf = wgrad_use_pf(g);
 #define LAUNCH_WG(KT_, NR_)                                                                                             \
@@ -1513,9 +1530,9 @@ int wgrad_patch_launch(const WgradPlan* p, const MdConvDesc* d, const float* src
           return MD_ERR_LAUNCH;                                                                                         \
         set8_ = true;                                                                                                   \
       }                                                                                                                 \
-      MD_KLAUNCH((k_wgrad_patch_pf<KT_, NR_, true>), grid, dim3(512), p->lds, s, g, src, ps, psh, slope, dy, slab);     \
+      MD_KLAUNCH((k_wgrad_patch_pf<KT_, NR_, true>), grid, dim3(512), p->lds, s, g, src, ps, psh, slope, dy, slab, ysplit); \
     } else if (pf)                                                                                                      \
-      MD_KLAUNCH((k_wgrad_patch_pf<KT_, NR_>), grid, dim3(256), p->lds, s, g, src, ps, psh, slope, dy, slab);   \
+      MD_KLAUNCH((k_wgrad_patch_pf<KT_, NR_>), grid, dim3(256), p->lds, s, g, src, ps, psh, slope, dy, slab, ysplit); \
     else                                                                                                                \
       MD_KLAUNCH((k_wgrad_patch<KT_, NR_>), grid, dim3(256), p->lds, s, g, src, ps, psh, slope, dy, slab, dbg); \
   } while (0)

@@ -57,6 +57,7 @@ __global__ __launch_bounds__(512) void k_conv_pers(
   const bool prologue = pscale != nullptr;
   const bool stats = stat_partial != nullptr;
   const int dbg = (accumulate >> 8) & 0xff;         // timing experiments (MD_DBG): 1 no patch loads, 2 no matrix loop, 4 no stores, 8 no commit
+  const bool presplit = (accumulate >> 16) & 1;      // source = pre-split bf16 gradient [pixel][C8]{hi | lo}: the commit is a plain copy
   accumulate &= 1;
 
   // ---- tables (once per workgroup)
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(512) void k_conv_pers(
       const int ppt = mdiv(pixel, g.m_pyx); const int r = pixel - ppt * g.pyx;
       const int ppy = mdiv(r, g.m_px); const int ppx = r - ppy * g.px;
       it_lds[u] = pixel * g.ppitch + c8 * 16;
-      it_rel[u] = ((ppt * g.Hs + ppy) * g.Ws + ppx) * g.Cps + c8 * 8;
+      it_rel[u] = presplit ? (((ppt * g.Hs + ppy) * g.Ws + ppx) * g.C8 + c8) * 8 : ((ppt * g.Hs + ppy) * g.Ws + ppx) * g.Cps + c8 * 8;
       it_pd[u] = (unsigned)ppt | ((unsigned)ppy << 6) | ((unsigned)ppx << 15) | ((unsigned)c8 << 24) |
                  ((c8 * 2 < cvalid4 ? 1u : 0u) << 30) | ((c8 * 2 + 1 < cvalid4 ? 1u : 0u) << 31);
     }
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(512) void k_conv_pers(
 #pragma unroll
   for (int j = 0; j < NREP; ++j) { s1[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; s2[j] = s1[j]; }
 
-  const __amdgpu_buffer_rsrc_t srs = make_rsrc(src, g.src_bytes);
+  const __amdgpu_buffer_rsrc_t srs = make_rsrc(src, presplit ? (unsigned)(g.src_bytes / (g.Cps * 4u)) * (unsigned)g.C8 * 32u : g.src_bytes);
   const __amdgpu_buffer_rsrc_t drs = make_rsrc(dst, g.dst_bytes);
   const __amdgpu_buffer_rsrc_t yrs = make_rsrc(FUSE ? bw.yraw : dst, g.dst_bytes);
 
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(512) void k_conv_pers(
     const int q2 = mdiv(b, pg.m_nby); const int yb = b - q2 * g.nby; b = q2;
     const int n = mdiv(b, pg.m_nbt); const int tb = b - n * g.nbt;
     const int ot = tb * g.bt * g.st + g.org_t, oh = yb * g.by * g.sh + g.org_h, ow = xb * g.bx * g.sw + g.org_w;
-    const int qbase = (((n * g.Ts + ot) * g.Hs + oh) * g.Ws + ow) * g.Cps;
+    const int qbase = (((n * g.Ts + ot) * g.Hs + oh) * g.Ws + ow) * (presplit ? g.C8 * 8 : g.Cps);
     inmask = 0;
 #pragma unroll
     for (int u = 0; u < MAXI; ++u) {
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(512) void k_conv_pers(
                         ((unsigned)sx_ < (unsigned)g.Ws) && ((pd >> 30) & 1u) && !(dbg & 1);
         const unsigned off = (unsigned)(qbase + it_rel[u]) * 4u;
         va[u] = buf_load4_pinned(srs, in ? off : MD_OOB);
-        vb[u] = buf_load4_pinned(srs, (in && (pd >> 31)) ? off + 16u : MD_OOB);
+        vb[u] = buf_load4_pinned(srs, (in && ((pd >> 31) || presplit)) ? off + 16u : MD_OOB);
         inmask |= (in ? 1u : 0u) << u;
       }
     }
@@ -195,7 +196,8 @@ __global__ __launch_bounds__(512) void k_conv_pers(
           }
         }
         uint4 hi, lo;
-        if (F16) split8_f16(v, hi, lo); else split8(v, hi, lo);
+        if (presplit) { hi = __builtin_bit_cast(uint4, va[u]); lo = __builtin_bit_cast(uint4, vb[u]); }
+        else if (F16) split8_f16(v, hi, lo); else split8(v, hi, lo);
         *(uint4*)(sP + it_lds[u]) = hi;
         *(uint4*)(sP + g.lo_off + it_lds[u]) = lo;
       }
@@ -416,7 +418,7 @@ int pers_launch(const PersGeom& pg, size_t lds, int grid, bool f16, const float*
   const int nrep = g.N16 / 16;
   const int nblk = pers_blocks(pg, grid);
   static const int dbg = getenv("MD_DBG") ? atoi(getenv("MD_DBG")) : 0;
-  accumulate = (accumulate & 1) | ((dbg & 0xff) << 8);
+  accumulate = (accumulate & 0x10001) | ((dbg & 0xff) << 8);
 #define LAUNCH_PERS(F16_, FUSE_, NR_, MX_)                                                                              \
   do {                                                                                                                  \
     static bool set_ = false;                                                                                           \

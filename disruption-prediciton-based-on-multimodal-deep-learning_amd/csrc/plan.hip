@@ -24,6 +24,7 @@ struct Unit {
   int64_t rows;     // output pixels
   size_t raw_off, stat_off, wf_off, wd_off;   // float offsets into the workspace
   int Cp;
+  int split;        // d_raw of this unit is kept in the pre-split bf16 format (md_bn_bwd_apply_fmt)
 };
 struct Block {
   int c1s, c1t, c2s, c2t, dss, dst;   // unit ids (dss/dst = -1 without downsample)
@@ -204,6 +205,7 @@ extern "C" int md_plan_create(int32_t B, int32_t T, int32_t H, int32_t W, const 
   P->coef_off = take(2 * 1024);
   P->gmax = gmax;
   P->red_blocks.assign(P->units.size(), 0);
+  for (size_t i = 0; i < P->units.size(); ++i) P->units[i].split = md_conv_split_dy_ok(&P->units[i].d, i != 0 ? 1 : 0);
   for (int i = 0; i < 4; ++i) P->g_off[i] = take(gmax);
   P->total_floats = off;
   *out = P;
@@ -424,13 +426,13 @@ static int unit_backward(MdPlan* P, float* ws, int ui, int gb, int dxb, int accu
     if (P->red_blocks[ui] > 0) {
       // the consumer's data gradient already reduced: G holds g, the partial buffer its sums
       RC(md_bn_bwd_finalize(ws + P->part_off, P->red_blocks[ui], u.d.Cout, u.rows, dgamma[ui], dbeta[ui], ws + P->coef_off, stream));
-      RC(md_bn_bwd_apply_g(G, &mainv, st, st + u.Cp, ws + P->coef_off, u.rows, u.d.Cout, G, stream));
+      RC(md_bn_bwd_apply_fmt(G, 1, &mainv, nullptr, 1.f, st, st + u.Cp, ws + P->coef_off, u.rows, u.d.Cout, G, u.split, nullptr, stream));
       P->red_blocks[ui] = 0;
     } else {
       const int nb = md_bn_bwd_blocks(u.rows, u.d.Cout);
       RC(md_bn_bwd_reduce(G, &mainv, nullptr, 1.f, st, st + u.Cp, u.rows, u.d.Cout, ws + P->part_off, stream));
       RC(md_bn_bwd_finalize(ws + P->part_off, nb, u.d.Cout, u.rows, dgamma[ui], dbeta[ui], ws + P->coef_off, stream));
-      RC(md_bn_bwd_apply(G, &mainv, nullptr, 1.f, st, st + u.Cp, ws + P->coef_off, u.rows, u.d.Cout, G, nullptr, stream));
+      RC(md_bn_bwd_apply_fmt(G, 0, &mainv, nullptr, 1.f, st, st + u.Cp, ws + P->coef_off, u.rows, u.d.Cout, G, u.split, nullptr, stream));
     }
   }
   MdActView in = unit_in_view(P, ws, ui);
@@ -440,12 +442,12 @@ static int unit_backward(MdPlan* P, float* ws, int ui, int gb, int dxb, int accu
     if (hipEventRecord(ready, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(P->side, ready, 0) != hipSuccess)
       return MD_ERR_LAUNCH;
     { ProfScope ps(P, KC_WGRAD, unit_flops(u), P->side);
-      RC(md_conv_wgrad(&u.d, &in, G, dw[ui], ws + P->slab_off, P->side)); }
+      RC(md_conv_wgrad_fmt(&u.d, &in, G, u.split, dw[ui], ws + P->slab_off, P->side)); }
     if (hipEventRecord(P->ev_done[gb], P->side) != hipSuccess) return MD_ERR_LAUNCH;
     P->done_pending[gb] = true; P->side_used = true;
   } else {
     ProfScope ps(P, KC_WGRAD, unit_flops(u), stream);
-    RC(md_conv_wgrad(&u.d, &in, G, dw[ui], ws + P->slab_off, stream));
+    RC(md_conv_wgrad_fmt(&u.d, &in, G, u.split, dw[ui], ws + P->slab_off, stream));
   }
   if (dxb >= 0) {
     RC(await_buffer(P, dxb, stream));
@@ -460,10 +462,10 @@ static int unit_backward(MdPlan* P, float* ws, int ui, int gb, int dxb, int accu
       const Unit& tu = P->units[target];
       MdActView tv = unit_out_view(P, ws, target);
       float* tst = ws + tu.stat_off;
-      RC(md_conv_dgrad_bnred(&u.d, G, ws + u.wd_off, ws + P->g_off[dxb], accumulate, &tv, tst, tst + tu.Cp, ws + P->part_off, stream));
+      RC(md_conv_dgrad_fmt(&u.d, G, u.split, ws + u.wd_off, ws + P->g_off[dxb], accumulate, &tv, tst, tst + tu.Cp, ws + P->part_off, stream));
       P->red_blocks[target] = nbr;
     } else {
-      RC(md_conv_dgrad(&u.d, G, ws + u.wd_off, ws + P->g_off[dxb], accumulate, stream));
+      RC(md_conv_dgrad_fmt(&u.d, G, u.split, ws + u.wd_off, ws + P->g_off[dxb], accumulate, nullptr, nullptr, nullptr, nullptr, stream));
     }
   }
   return MD_OK;
@@ -485,8 +487,8 @@ static int block_backward(MdPlan* P, float* ws, const Block& b, const float* con
   RC(md_bn_bwd_finalize(ws + P->part_off, nb, t2.d.Cout, t2.rows, dgamma[b.c2t], dbeta[b.c2t], ws + P->coef_off, stream));
   RC(await_buffer(P, a, stream));
   RC(await_buffer(P, p, stream));
-  RC(md_bn_bwd_apply(Gp, &mainv, &skipv, P->alpha, st, st + t2.Cp, ws + P->coef_off, t2.rows, t2.d.Cout,
-                     ws + P->g_off[a], Gp, stream));
+  RC(md_bn_bwd_apply_fmt(Gp, 0, &mainv, &skipv, P->alpha, st, st + t2.Cp, ws + P->coef_off, t2.rows, t2.d.Cout,
+                         ws + P->g_off[a], t2.split, Gp, stream));
   RC(unit_backward(P, ws, b.c2t, a, bb, 0, true, w, dw, dgamma, dbeta, stream));
   RC(unit_backward(P, ws, b.c2s, bb, a, 0, false, w, dw, dgamma, dbeta, stream));
   RC(unit_backward(P, ws, b.c1t, a, bb, 0, false, w, dw, dgamma, dbeta, stream));

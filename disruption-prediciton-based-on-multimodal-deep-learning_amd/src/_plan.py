@@ -104,21 +104,29 @@ class TrunkFunction(torch.autograd.Function):
     """feat = R2Plus1DNet(x); parameters are passed flat as [w_0.., gamma_0.., beta_0..]."""
 
     @staticmethod
-    def forward(ctx, plan: TrunkPlan, x, rmeans, rvars, training, seg_hook, *params):
+    def forward(ctx, plan: TrunkPlan, x, rmeans, rvars, training, need_bwd, seg_hook, *params):
+        """``need_bwd`` is decided by the CALLER (grad mode is always off inside an autograd.Function's forward): when a
+        backward may follow, the activations live in a workspace of their own that this node owns until its backward has
+        run; otherwise the plan's cached scratch workspace is used."""
         n = plan.num_units
         weights, gammas, betas = params[:n], params[n:2 * n], params[2 * n:3 * n]
         require_cuda(x, *params)
-        need_bwd = training and torch.is_grad_enabled()
         ws = plan.new_workspace(x.device) if need_bwd else plan.eval_workspace(x.device)
         feat = plan.forward(x, ws, weights, gammas, betas, rmeans, rvars, training)
         ctx.plan = plan
-        ctx.ws = ws
+        ctx.ws = ws if need_bwd else None
+        ctx.training = bool(training)
         ctx.seg_hook = seg_hook
         ctx.params = params
         return feat
 
     @staticmethod
     def backward(ctx, dfeat):
+        if not ctx.training:
+            raise RuntimeError("R2Plus1DNet: backward through an eval-mode forward is not supported on the MI355X path "
+                               "(BatchNorm uses running statistics there; call model.train() or wrap the forward in no_grad)")
+        if ctx.ws is None:
+            raise RuntimeError("R2Plus1DNet: this forward was run without saving activations (no parameter required a gradient)")
         plan: TrunkPlan = ctx.plan
         n = plan.num_units
         params = ctx.params
@@ -149,4 +157,4 @@ class TrunkFunction(torch.autograd.Function):
             finally:
                 plan.defer_join(False)
         ctx.ws = None
-        return (None, None, None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None, None, None) + tuple(grads)

@@ -184,7 +184,9 @@ class R2Plus1DNet(nn.Module):
         bs = [u.bn.bias for u in units]
         rms = [u.bn.running_mean for u in units]
         rvs = [u.bn.running_var for u in units]
-        feat = TrunkFunction.apply(plan, x, rms, rvs, self.training, self.grad_segment_hook, *ws, *gs, *bs)
+        # a backward can follow only if grad mode is on and something upstream of the features requires a gradient
+        need_bwd = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in ws + gs + bs))
+        feat = TrunkFunction.apply(plan, x, rms, rvs, self.training, need_bwd, self.grad_segment_hook, *ws, *gs, *bs)
         if self.training:
             torch._foreach_add_([u.bn.num_batches_tracked for u in units], 1)
         return feat

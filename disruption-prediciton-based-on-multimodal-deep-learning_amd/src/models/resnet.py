@@ -2,13 +2,9 @@
 
 Built here: ``SwishEfficient`` / ``Swish`` (resnet.py:63-81) on ``md_swish_fwd`` / ``md_swish_bwd`` , ``Bottleneck3D``
 (resnet.py:121-200) and the ``ResNet3D`` base (resnet.py:202-273).  The rest of that module
-(BasicBlock3D, SubBatchNorm3d, Bottleneck2DPlus1D, ...) is not used by the SlowFast configuration and is not rebuilt.  When ``MD_REFERENCE_SRC`` points at the reference's ``src`` directory those names are
-loaded from the reference file and re-exported with ITS ``Swish`` / ``SwishEfficient`` / ``Bottleneck3D`` replaced by the ones below, so
-``from src.models.resnet import *`` (slowfast.py:5) keeps working and the reference's SlowFast runs its Swish on the
-gfx950 kernel.  Without it this module exports the two native names only.
+(BasicBlock3D, SubBatchNorm3d, Bottleneck2DPlus1D, ...) is dead code in the reference (never
+constructed by any configuration) and is not rebuilt; this module never loads or executes reference source.
 """
-import importlib.util as _ilu
-import os as _os
 
 import torch
 import torch.nn as nn
@@ -248,23 +244,3 @@ class ResNet3D(nn.Module):
             layers.append(block(self.inplanes, planes, head_conv=head_conv, base_bn_splits=base_bn_splits))
         self.inplanes += self.slow * block.expansion * planes // self.alpha
         return nn.Sequential(*layers)
-
-
-def _adopt_reference():
-    ref = _os.environ.get("MD_REFERENCE_SRC")
-    path = _os.path.join(ref, "models", "resnet.py") if ref else None
-    if not path or not _os.path.isfile(path):
-        return
-    spec = _ilu.spec_from_file_location("src.models._reference_resnet", path)
-    mod = _ilu.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    mod.Swish = Swish
-    mod.SwishEfficient = SwishEfficient
-    g = globals()
-    for name in dir(mod):
-        if not name.startswith("_") and name not in ("Swish", "SwishEfficient", "Bottleneck3D", "ResNet3D"):
-            g.setdefault(name, getattr(mod, name))
-    mod.Bottleneck3D = Bottleneck3D
-
-
-_adopt_reference()

@@ -149,6 +149,38 @@ def bn_backward_from_g(g: torch.Tensor, part: torch.Tensor, main: N.MdActView, s
     return d_raw, dgamma, dbeta
 
 
+def bn_apply_fmt(dA: torch.Tensor, main: N.MdActView, st: torch.Tensor, coef: torch.Tensor, Cc: int, split_out: bool,
+                 g_in: bool = False) -> torch.Tensor:
+    """The apply pass of BatchNorm-backward alone (md_bn_bwd_apply_fmt): d_raw in fp32 or in the pre-split bf16 format
+    (same bytes; returned as a float32-typed tensor either way)."""
+    require_cuda(dA, st, coef)
+    rows = dA.numel() // dA.shape[-1]
+    out = torch.empty_like(dA)
+    N.check(N.lib().md_bn_bwd_apply_fmt(_p(dA), int(g_in), C.byref(main), None, 1.0, _p(st[0]), _p(st[1]), _p(coef), rows, Cc,
+                                        _p(out), int(split_out), None, _stream()), "md_bn_bwd_apply_fmt")
+    return out
+
+
+def conv_dgrad_fmt(d: N.MdConvDesc, dy: torch.Tensor, dy_split: bool, wd: torch.Tensor, out: Optional[torch.Tensor] = None,
+                   accumulate: bool = False) -> torch.Tensor:
+    require_cuda(dy, wd, out)
+    if out is None:
+        out = torch.empty((d.N, d.Ti, d.Hi, d.Wi, cpad(d.Cin)), device=dy.device, dtype=torch.float32)
+        accumulate = False
+    N.check(N.lib().md_conv_dgrad_fmt(C.byref(d), _p(dy), int(dy_split), _p(wd), _p(out), int(accumulate), None, None, None, None,
+                                      _stream()), "md_conv_dgrad_fmt")
+    return out
+
+
+def conv_wgrad_fmt(d: N.MdConvDesc, x: N.MdActView, dy: torch.Tensor, dy_split: bool) -> torch.Tensor:
+    require_cuda(dy)
+    dw = torch.empty((d.Cout, d.Cin, d.kt, d.kh, d.kw), device=dy.device, dtype=torch.float32)
+    nws = N.lib().md_conv_wgrad_workspace_floats(C.byref(d))
+    ws = torch.empty(nws, device=dy.device, dtype=torch.float32) if nws else None
+    N.check(N.lib().md_conv_wgrad_fmt(C.byref(d), C.byref(x), _p(dy), int(dy_split), _p(dw), _p(ws), _stream()), "md_conv_wgrad_fmt")
+    return dw
+
+
 def conv_wgrad(d: N.MdConvDesc, x: N.MdActView, dy: torch.Tensor) -> torch.Tensor:
     require_cuda(dy)
     dw = torch.empty((d.Cout, d.Cin, d.kt, d.kh, d.kw), device=dy.device, dtype=torch.float32)

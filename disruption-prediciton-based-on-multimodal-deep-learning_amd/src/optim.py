@@ -5,7 +5,8 @@ The reference's step is ``torch.nn.utils.clip_grad_norm_(model.parameters(), max
 parameter tensors that is a chain of multi-tensor launches (~0.4 ms per step on MI355X); ``ClipAdamW`` does the same
 arithmetic through ``md_opt_grad_norm`` + ``md_opt_adamw_step`` (include/mi355x_disrupt.h), which walk a device table of
 all tensors.  Hyper-parameters, defaults and the update rule are those of ``torch.optim.AdamW`` (no amsgrad, no
-maximize); ``state_dict`` holds ``exp_avg`` / ``exp_avg_sq`` per parameter and ``step`` per group.
+maximize); ``state_dict`` holds ``exp_avg`` / ``exp_avg_sq`` / ``step`` per parameter (``step`` as a Python int; the group's
+``step`` mirrors the largest for information).
 
 The training loops of this package (src/train.py, src/distributed.py) recognise ``fused_clip`` and hand the clip
 threshold to ``step(max_norm=...)`` instead of calling ``clip_grad_norm_`` themselves.
@@ -39,17 +40,26 @@ class ClipAdamW(torch.optim.Optimizer):
     # ------------------------------------------------------------------ tables
     _RING = 4      # pinned staging buffers per group: the host may run this many table refreshes ahead of the device
 
-    def _tables(self, gi: int, group):
-        """Device tables for one parameter group: (key, tensor table, chunk table, #chunks, scratch).
+    def _tables(self, slot_key, ps):
+        """Device tables for one set of parameters that share a step count: (tensor table, chunk table, #chunks, scratch).
 
         The chunk table depends on the parameter sizes only.  The tensor table holds raw pointers; gradient tensors are
-        re-created by autograd every step and some change address, so the table is refreshed whenever a pointer moved --
-        through pinned staging buffers and an asynchronous copy on the current stream, never a host synchronisation."""
-        ps = [p for p in group["params"] if p.grad is not None]
-        if not ps:
-            return None
-        key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps)
-        hit = self._cache.get(gi)
+        re-created by autograd every step and some change address, and ``load_state_dict`` replaces the moment tensors, so
+        the table is refreshed whenever ANY of the four pointers of a parameter moved -- through pinned staging buffers and
+        an asynchronous copy on the current stream, never a host synchronisation."""
+        for p in ps:
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                raise RuntimeError("ClipAdamW: parameters must be contiguous CUDA float32 (no CPU fallback)")
+            g = p.grad
+            if not (g.is_cuda and g.dtype == torch.float32 and g.is_contiguous()):
+                raise RuntimeError("ClipAdamW: gradients must be contiguous CUDA float32 (no CPU fallback)")
+            st = self.state[p]
+            if "exp_avg" not in st:
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr())
+                    for p in ps)
+        hit = self._cache.get(slot_key)
         if hit is not None and hit["key"] == key:
             return hit
         ids = tuple(id(p) for p in ps)
@@ -59,13 +69,7 @@ class ClipAdamW(torch.optim.Optimizer):
             tens = np.zeros(len(ps), dtype=_TENSOR_DT)
             chunks = []
             for i, p in enumerate(ps):
-                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
-                    raise RuntimeError("ClipAdamW: parameters must be contiguous CUDA float32 (no CPU fallback)")
-                st = self.state[p]
-                if "exp_avg" not in st:
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                tens[i] = (0, 0, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
+                tens[i] = (0, 0, 0, 0, p.numel())
                 chunks.extend((i, o) for o in range((p.numel() + chunk - 1) // chunk))
             ch = np.array(chunks, dtype=_CHUNK_DT)
             nbytes = tens.nbytes
@@ -77,14 +81,12 @@ class ClipAdamW(torch.optim.Optimizer):
                 "pinned": [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(self._RING)],
                 "events": [None] * self._RING, "slot": 0,
             }
-            self._cache[gi] = hit
-        for p in ps:
-            g = p.grad
-            if not (g.is_cuda and g.dtype == torch.float32 and g.is_contiguous()):
-                raise RuntimeError("ClipAdamW: gradients must be contiguous CUDA float32 (no CPU fallback)")
+            self._cache[slot_key] = hit
         tens = hit["host"]
         tens["p"] = [k[0] for k in key]
         tens["g"] = [k[1] for k in key]
+        tens["m"] = [k[2] for k in key]
+        tens["v"] = [k[3] for k in key]
         slot = hit["slot"]; hit["slot"] = (slot + 1) % self._RING
         if hit["events"][slot] is not None:
             hit["events"][slot].synchronize()             # this staging buffer's previous copy (4 refreshes ago) is done
@@ -94,6 +96,15 @@ class ClipAdamW(torch.optim.Optimizer):
         ev = torch.cuda.Event(); ev.record(); hit["events"][slot] = ev
         hit["key"] = key
         return hit
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._cache.clear()                                   # the moment tensors were replaced
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        if hasattr(self, "_cache"):
+            self._cache.clear()
 
     # ------------------------------------------------------------------ step
     @torch.no_grad()
@@ -105,22 +116,40 @@ class ClipAdamW(torch.optim.Optimizer):
         max_norm = self.max_norm if max_norm is None else max_norm
         L = N.lib()
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        live = [(g, self._tables(i, g)) for i, g in enumerate(self.param_groups)]
-        live = [(g, t) for g, t in live if t is not None]
-        if max_norm and len(live) > 1:
+        # Parameters that received a gradient, partitioned by their own step count (torch.optim.AdamW keeps ``step`` per
+        # parameter: one that gets its first gradient late starts its bias correction at 1).  Normally one partition per group.
+        work = []
+        for gi, group in enumerate(self.param_groups):
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            by_step = {}
+            for p in ps:
+                by_step.setdefault(int(self.state[p].get("step", 0)), []).append(p)
+            for st_count, sub in sorted(by_step.items()):
+                work.append((gi, group, st_count, sub))
+        groups_with_work = sorted({gi for gi, _, _, _ in work})
+        if max_norm and len(groups_with_work) > 1:
             raise RuntimeError("ClipAdamW: gradient clipping across several parameter groups is not supported")
-        for group, tb in live:
-            tens, chunks, nch, partial = tb["tens"], tb["chunks"], tb["nch"], tb["partial"]
-            coef = None
-            if max_norm:
-                N.check(L.md_opt_grad_norm(C.c_void_p(tens.data_ptr()), C.c_void_p(chunks.data_ptr()), nch, float(max_norm),
-                                           C.c_void_p(partial[2:].data_ptr()), C.c_void_p(partial.data_ptr()), stream),
-                        "md_opt_grad_norm")
-                coef = C.c_void_p(partial.data_ptr())
-                self.last_grad_norm = partial[0]
-            group["step"] += 1
+        coef = None
+        if max_norm and work:
+            # one norm over every parameter that has a gradient (all partitions of the group)
+            allp = [p for _, _, _, sub in work for p in sub]
+            tb = self._tables((work[0][0], -1), allp)
+            partial = tb["partial"]
+            N.check(L.md_opt_grad_norm(C.c_void_p(tb["tens"].data_ptr()), C.c_void_p(tb["chunks"].data_ptr()), tb["nch"],
+                                       float(max_norm), C.c_void_p(partial[2:].data_ptr()), C.c_void_p(partial.data_ptr()), stream),
+                    "md_opt_grad_norm")
+            coef = C.c_void_p(partial.data_ptr())
+            self.last_grad_norm = partial[0]
+        for gi, group, st_count, sub in work:
+            single = sum(1 for w in work if w[0] == gi) == 1
+            tb = self._tables((gi, -1 if single else st_count), sub)
+            for p in sub:
+                self.state[p]["step"] = st_count + 1
             b1, b2 = group["betas"]
-            N.check(L.md_opt_adamw_step(C.c_void_p(tens.data_ptr()), C.c_void_p(chunks.data_ptr()), nch, coef,
+            N.check(L.md_opt_adamw_step(C.c_void_p(tb["tens"].data_ptr()), C.c_void_p(tb["chunks"].data_ptr()), tb["nch"], coef,
                                         float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                                        float(group["weight_decay"]), int(group["step"]), stream), "md_opt_adamw_step")
+                                        float(group["weight_decay"]), int(st_count + 1), stream), "md_opt_adamw_step")
+            group["step"] = max(int(group.get("step", 0)), st_count + 1)
         return loss

@@ -155,6 +155,27 @@ int md_conv_dgrad_bnred(const MdConvDesc* d, const float* dy_raw, const float* w
 int md_bn_bwd_apply_g(const float* g, const MdActView* main, const float* mean, const float* invstd, const float* coef,
                       int64_t rows, int32_t C, float* d_raw, void* stream);
 
+/* Pre-split gradient format.  The data-gradient and weight-gradient kernels multiply fp32 operands as two bf16 halves
+ * (hi = bf16(x), lo = bf16(x - hi)); splitting d_raw while it is staged into LDS costs them vector-ALU issue slots they
+ * are short of, and every d_raw is staged twice (by the unit's data gradient and by its weight gradient).  With
+ * split_out != 0 the apply pass -- an HBM-bound streaming kernel with idle ALUs -- writes d_raw already split:
+ * [pixel][ceil(C/8) chunks]{hi: 8 x bf16 | lo: 8 x bf16}, 32 bytes per 8 channels (the same bytes as fp32 when
+ * md_cpad(C) % 8 == 0, which is required; the pass may then run in place).  The consumers stage it with plain copies and
+ * produce bit-identical results.  md_conv_split_dy_ok(d, need_dgrad) says whether the kernels that will read the d_raw of
+ * convolution d (its weight gradient, and its data gradient when need_dgrad != 0) all accept the format.
+ * md_bn_bwd_apply_fmt generalises md_bn_bwd_apply (g_in = 0) and md_bn_bwd_apply_g (g_in = 1, skip must be NULL);
+ * md_conv_dgrad_fmt generalises md_conv_dgrad (y_view = NULL) and md_conv_dgrad_bnred; md_conv_wgrad_fmt md_conv_wgrad.
+ * Backward of Conv3dBlock, R2Plus1D.py:44-58. */
+int md_conv_split_dy_ok(const MdConvDesc* d, int need_dgrad);
+int md_bn_bwd_apply_fmt(const float* dA, int g_in, const MdActView* main, const MdActView* skip, float alpha,
+                        const float* mean, const float* invstd, const float* coef, int64_t rows, int32_t C,
+                        void* d_raw, int split_out, float* dS, void* stream);
+int md_conv_dgrad_fmt(const MdConvDesc* d, const void* dy, int dy_split, const float* wpack_dgrad, float* dx,
+                      int accumulate, const MdActView* y_view, const float* mean, const float* invstd,
+                      float* partial, void* stream);
+int md_conv_wgrad_fmt(const MdConvDesc* d, const MdActView* x, const void* dy, int dy_split, float* dw,
+                      float* workspace, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Boundary layout conversion, pooling, classifier head, losses.
  * ---------------------------------------------------------------------------------------------- */

@@ -199,3 +199,56 @@ def test_trunk_with_persistent_kernels_against_the_oracle():
         if e > max(1e-3, 3.0 * e32):
             bad.append((k, e, e32))
     assert not bad, bad
+
+
+SPLIT_CASES = [c for c in CASES if c[0] != "stem"] + [
+    ("wide144", 64, 144, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 3, 12, 12)),      # weight gradient split over several column groups
+    ("t144", 144, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 5, 8, 8)),
+    ("big", 32, 72, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 6, 40, 36)),            # enough boxes for the prefetching weight-gradient kernels
+]
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES, ids=[c[0] for c in SPLIT_CASES])
+@pytest.mark.parametrize("persistent", [False, True], ids=["per_box", "persistent"])
+def test_presplit_gradient_format_is_bit_identical(case, persistent):
+    """d_raw written by the apply pass in the pre-split bf16 format (md_bn_bwd_apply_fmt, split_out) and consumed by the data
+    gradient and the weight gradient with plain copies must give the SAME BITS as the fp32 tensor split while it is staged:
+    the halves come from the same split8() arithmetic."""
+    name, Cin, Cout, k, s, p, (Nn, T, H, W) = case
+    lib = N.lib()
+    prev = lib.md_set_pers_grid(3 if persistent else 0)
+    try:
+        g = torch.Generator().manual_seed(11 + sum(map(ord, name)))
+        d = ops.make_desc(Nn, T, H, W, Cin, Cout, k, s, p)
+        if ops.cpad(Cout) % 8:
+            pytest.skip("the pre-split format needs a channel pitch that is a multiple of 8")
+        x = torch.randn(Nn, Cin, T, H, W, generator=g)
+        w = torch.randn(Cout, Cin, *k, generator=g) / np.sqrt(Cin * k[0] * k[1] * k[2])
+        y = F.conv3d(x, w, None, s, p)                                   # raw output of the unit: BatchNorm input
+        dA = torch.randn(y.shape, generator=g) * torch.logspace(-6, 2, y.shape[1]).view(1, -1, 1, 1, 1)    # wide dynamic range
+        gamma = torch.rand(Cout, generator=g) + 0.5; beta = torch.randn(Cout, generator=g) * 0.3
+        mean, invstd = _bn_stats(y)
+        Cp = ops.cpad(Cout)
+        st = torch.zeros(4, Cp); st[0, :Cout] = mean; st[1, :Cout] = invstd
+        st[2, :Cout] = gamma * invstd; st[3, :Cout] = beta - mean * gamma * invstd
+        st = st.to(DEV)
+        coef = (torch.randn(2, Cp, generator=g) * 0.01).to(DEV); coef[:, Cout:] = 0
+        yg, dAg, xg = cl(y).to(DEV), cl(dA).to(DEV), cl(x).to(DEV)
+        yv = ops.view(yg, st[2], st[3], 0.01)
+        d32 = ops.bn_apply_fmt(dAg, yv, st, coef, Cout, split_out=False)
+        dsp = ops.bn_apply_fmt(dAg, yv, st, coef, Cout, split_out=True)
+        # the split tensor holds hi = bf16(x) and lo ~ bf16(x - hi) of the fp32 one, chunk by chunk: 16 significant bits
+        hi_lo = dsp.view(torch.bfloat16).view(-1, 2, 8).float()
+        ref = d32.view(-1, 8)
+        assert torch.equal(hi_lo[:, 0], ref.bfloat16().float())
+        assert float(((hi_lo[:, 0] + hi_lo[:, 1] - ref).abs() / ref.abs().clamp_min(1e-30)).max()) < 2.0 ** -15
+        _, wd = ops.pack_weights(d, w.to(DEV))
+        dx32 = ops.conv_dgrad_fmt(d, d32, False, wd)
+        dxsp = ops.conv_dgrad_fmt(d, dsp, True, wd)
+        assert torch.equal(dx32, dxsp), name
+        dw32 = ops.conv_wgrad_fmt(d, ops.view(xg), d32, False)
+        dwsp = ops.conv_wgrad_fmt(d, ops.view(xg), dsp, True)
+        torch.cuda.synchronize()
+        assert torch.equal(dw32, dwsp), name
+    finally:
+        lib.md_set_pers_grid(prev)

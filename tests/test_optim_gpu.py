@@ -38,6 +38,7 @@ def test_clip_adamw_matches_torch(max_norm, gscale):
             assert float((p - q).abs().max()) <= 2e-6 * max(1.0, float(p.abs().max())), (step, tuple(p.shape))
     sd = o_my.state_dict()
     assert sd["param_groups"][0]["step"] == 6 and len(sd["state"]) == len(SHAPES)
+    assert all(st["step"] == 6 for st in sd["state"].values())
 
 
 def test_clip_adamw_scheduler_and_missing_grads():
@@ -54,3 +55,48 @@ def test_clip_adamw_scheduler_and_missing_grads():
     with pytest.raises(RuntimeError):
         q = torch.ones(4, requires_grad=True); q.grad = torch.ones(4)
         ClipAdamW([q]).step()
+
+
+def test_state_dict_round_trip_and_late_first_gradient():
+    """ load_state_dict replaces the moment tensors: the cached device table must follow them, and a parameter
+    that receives its first gradient later than the others starts its own bias correction at step 1, as
+    torch.optim.AdamW does (``step`` is kept per parameter)."""
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(3)
+    shapes = [(33,), (5000,), (7, 9)]
+    ref = [torch.randn(s, generator=g).to(dev).requires_grad_(True) for s in shapes]
+    mine = [p.detach().clone().requires_grad_(True) for p in ref]
+    o_ref = torch.optim.AdamW(ref, lr=1e-2)
+    o_my = ClipAdamW(mine, lr=1e-2)
+
+    def step(with_last, max_norm):
+        grads = [torch.randn(s, generator=g).to(dev) for s in shapes]
+        for i, (p, q, gr) in enumerate(zip(ref, mine, grads)):
+            if i == 2 and not with_last:
+                p.grad = None; q.grad = None
+            else:
+                p.grad = gr.clone(); q.grad = gr.clone()
+        if max_norm:
+            torch.nn.utils.clip_grad_norm_([p for p in ref if p.grad is not None], max_norm)
+        o_ref.step(); o_my.step(max_norm=max_norm)
+
+    for _ in range(3):
+        step(False, 1.0)                      # the third parameter gets no gradient yet
+    step(True, 1.0)                           # ... and now its first one: two step counts in one group, clipping active
+    step(True, None)
+    # round trip through state_dict into fresh optimizers that have already stepped once (so their tables are cached)
+    sd_ref, sd_my = o_ref.state_dict(), o_my.state_dict()
+    ref2 = [p.detach().clone().requires_grad_(True) for p in ref]; mine2 = [p.detach().clone().requires_grad_(True) for p in mine]
+    o_ref2 = torch.optim.AdamW(ref2, lr=1e-2); o_my2 = ClipAdamW(mine2, lr=1e-2)
+    for p, q in zip(ref2, mine2):
+        p.grad = torch.zeros_like(p); q.grad = torch.zeros_like(q)
+    o_my2.step(); o_ref2.step()
+    with torch.no_grad():
+        for a, b in zip(ref2, ref): a.copy_(b)
+        for a, b in zip(mine2, mine): a.copy_(b)
+    o_ref2.load_state_dict(sd_ref); o_my2.load_state_dict(sd_my)
+    ref, mine, o_ref, o_my = ref2, mine2, o_ref2, o_my2
+    for _ in range(2):
+        step(True, 0.5)
+    for p, q in zip(ref, mine):
+        assert float((p - q).abs().max()) <= 5e-6 * max(1.0, float(p.abs().max())), tuple(p.shape)

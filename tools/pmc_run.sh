@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (on the GPU box): bash tools/pmc_run.sh <layer> <op> <tag>   -> gpurun_out/pmc_<tag>/p{1,2,3}
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out/pmc_$3
 P1="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD"
 P2="SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
 P3="SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_VALU_CVT SQ_INST_CYCLES_VMEM_RD GRBM_GUI_ACTIVE SQ_INSTS_VMEM_WR"

@@ -232,6 +232,23 @@ extern "C" int md_plan_unit_desc(const MdPlan* p, int32_t i, MdConvDesc* out) {
   return MD_OK;
 }
 extern "C" size_t md_plan_workspace_bytes(const MdPlan* p) { return p ? p->total_floats * 4 : 0; }
+// Where a forward leaves things in the workspace (float offsets), for diagnostics that compare intermediate tensors
+// with the oracle: unit i's raw conv output [rows][Cp] and its [mean | invstd | scale | shift][Cp] statistics block.
+extern "C" int md_plan_unit_layout(const MdPlan* p, int32_t i, size_t* raw_off, size_t* stat_off, int64_t* rows, int32_t* Cp) {
+  if (!p || !raw_off || !stat_off || !rows || !Cp) return MD_ERR_NULL;
+  if (i < 0 || i >= (int)p->units.size()) return MD_ERR_BAD_SHAPE;
+  const Unit& u = p->units[i];
+  *raw_off = u.raw_off; *stat_off = u.stat_off; *rows = u.rows; *Cp = u.Cp;
+  return MD_OK;
+}
+// Materialised tensor zi (0: the clip in channels-last, 1: the stem output, then one per residual block): [rows][md_cpad(C)].
+extern "C" int32_t md_plan_num_z(const MdPlan* p) { return p ? (int32_t)p->z.size() : 0; }
+extern "C" int md_plan_z_layout(const MdPlan* p, int32_t zi, size_t* off, int64_t* rows, int32_t* C) {
+  if (!p || !off || !rows || !C) return MD_ERR_NULL;
+  if (zi < 0 || zi >= (int)p->z.size()) return MD_ERR_BAD_SHAPE;
+  *off = p->z[zi].off; *rows = p->z[zi].rows; *C = p->z[zi].C;
+  return MD_OK;
+}
 extern "C" int32_t md_plan_feat_dim(const MdPlan* p) { return p ? p->feat_dim : 0; }
 
 #define RC(x) do { int rc__ = (x); if (rc__ != MD_OK) return rc__; } while (0)

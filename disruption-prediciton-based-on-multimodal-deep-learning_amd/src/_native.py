@@ -75,6 +75,9 @@ SIGNATURES = {
     "md_plan_num_units": (_I32, [_P]),
     "md_plan_unit_desc": (C.c_int, [_P, _I32, _DESC]),
     "md_plan_workspace_bytes": (_SZ, [_P]),
+    "md_plan_unit_layout": (C.c_int, [_P, _I32, C.POINTER(_SZ), C.POINTER(_SZ), C.POINTER(_I64), C.POINTER(_I32)]),
+    "md_plan_num_z": (_I32, [_P]),
+    "md_plan_z_layout": (C.c_int, [_P, _I32, C.POINTER(_SZ), C.POINTER(_I64), C.POINTER(_I32)]),
     "md_plan_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P]),
     "md_plan_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "md_plan_backward_range": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P]),

@@ -77,6 +77,23 @@ class TrunkPlan:
         d = self.descs[i]
         return (d.Cout, d.Cin, d.kt, d.kh, d.kw)
 
+    def unit_tensors(self, ws: torch.Tensor, i: int):
+        """Diagnostics: views into a workspace a forward has filled -- (raw conv output [rows, Cp], stats [4, Cp] =
+        mean | invstd | scale | shift) of unit i."""
+        ro, so, rows, cp = C.c_size_t(), C.c_size_t(), C.c_int64(), C.c_int32()
+        N.check(N.lib().md_plan_unit_layout(self._h, i, C.byref(ro), C.byref(so), C.byref(rows), C.byref(cp)), "md_plan_unit_layout")
+        f = ws.view(torch.float32)
+        raw = f[ro.value:ro.value + rows.value * cp.value].view(rows.value, cp.value)
+        st = f[so.value:so.value + 4 * cp.value].view(4, cp.value)
+        return raw, st
+
+    def z_tensor(self, ws: torch.Tensor, zi: int):
+        """Diagnostics: materialised tensor zi of a filled workspace, [rows, cpad(C)], and C."""
+        off, rows, cc = C.c_size_t(), C.c_int64(), C.c_int32()
+        N.check(N.lib().md_plan_z_layout(self._h, zi, C.byref(off), C.byref(rows), C.byref(cc)), "md_plan_z_layout")
+        cp = (cc.value + 3) & ~3
+        return ws.view(torch.float32)[off.value:off.value + rows.value * cp].view(rows.value, cp), cc.value
+
     def new_workspace(self, device) -> torch.Tensor:
         return torch.empty(self.workspace_bytes, dtype=torch.uint8, device=device)
 

@@ -345,6 +345,13 @@ int32_t md_plan_num_units(const MdPlan* p);
 int md_plan_unit_desc(const MdPlan* p, int32_t i, MdConvDesc* out);
 /* Device memory the plan needs (bytes): activations kept for backward + scratch. */
 size_t md_plan_workspace_bytes(const MdPlan* p);
+/* Diagnostics: where md_plan_forward leaves intermediate tensors in the workspace (offsets in floats).  Unit i: raw conv
+ * output [rows][Cp] and the statistics block [mean | invstd | scale | shift][Cp]; materialised tensor zi (0 = the clip in
+ * channels-last, 1 = the stem output, then one per residual block): [rows][md_cpad(C)].  Used by tools/kink_diag.py to
+ * compare LeakyReLU pre-activations with the oracle's, element by element. */
+int md_plan_unit_layout(const MdPlan* plan, int32_t unit, size_t* raw_off, size_t* stat_off, int64_t* rows, int32_t* Cp);
+int32_t md_plan_num_z(const MdPlan* plan);
+int md_plan_z_layout(const MdPlan* plan, int32_t zi, size_t* off, int64_t* rows, int32_t* C);
 /* Parameter / gradient / buffer tables: arrays of device pointers indexed by unit:
  *   w[i] (Cout,Cin,kt,kh,kw), gamma[i], beta[i], running_mean[i], running_var[i] (may be NULL). */
 int md_plan_forward(MdPlan* p, const float* x_ncthw, const float* const* w, const float* const* gamma,

@@ -76,37 +76,59 @@ def _bn(y: torch.Tensor, sd: Dict[str, torch.Tensor], bufs: Dict[str, torch.Tens
         sd[name + ".weight"], sd[name + ".bias"], training, BN_MOMENTUM, BN_EPS)
 
 
-def run_unit(x, u: ConvUnit, sd, bufs, training: bool):
+def _leaky(pre, slope: float, name: str, tap, force):
+    """LeakyReLU with two diagnostic hooks (tests/kink_util.py).  ``tap[name]`` receives the pre-activation; ``force[name]``
+    (bool, True = positive branch) replaces the sign test, i.e. evaluates the SAME piecewise-linear function on a given
+    activation pattern -- used to check that two evaluations differ only by which side of zero a few near-zero
+    pre-activations fell on (LeakyReLU's derivative jumps by 1/slope there)."""
+    if tap is not None:
+        tap[name] = pre.detach()
+    if force is not None and name in force:
+        return torch.where(force[name], pre, pre * slope)
+    return F.leaky_relu(pre, slope)
+
+
+def run_unit(x, u: ConvUnit, sd, bufs, training: bool, tap=None, force=None):
     y = F.conv3d(x, sd[u.name + ".conv.weight"], None, u.stride, u.padding)
     y = _bn(y, sd, bufs, u.name + ".bn", training)
     if training and (u.name + ".bn.num_batches_tracked") in bufs:
         bufs[u.name + ".bn.num_batches_tracked"] += 1
-    return F.leaky_relu(y, u.slope)
+    return _leaky(y, u.slope, u.name, tap, force)
 
 
-def res_block(x, prefix: str, cin: int, cout: int, downsample: bool, alpha: float, sd, bufs, training: bool):
+def res_block(x, prefix: str, cin: int, cout: int, downsample: bool, alpha: float, sd, bufs, training: bool,
+              tap=None, force=None):
     """SpatioTemporalResBlock.forward (R2Plus1D.py:181-187)."""
     s = 2 if downsample else 1
     r = x
     for u in st_conv_units(prefix + ".conv1", cin, cout, 3, s, 1):
-        r = run_unit(r, u, sd, bufs, training)
+        r = run_unit(r, u, sd, bufs, training, tap, force)
     for u in st_conv_units(prefix + ".conv2", cout, cout, 3, 1, 1):
-        r = run_unit(r, u, sd, bufs, training)
+        r = run_unit(r, u, sd, bufs, training, tap, force)
     if downsample:
         for u in st_conv_units(prefix + ".downsample_conv", cin, cout, 1, 2, 0):
-            x = run_unit(x, u, sd, bufs, training)
-    return F.leaky_relu(x + r, alpha)
+            x = run_unit(x, u, sd, bufs, training, tap, force)
+    return _leaky(x + r, alpha, prefix + ".relu", tap, force)
 
 
-def trunk_forward(x, sd, bufs, layer_sizes, alpha: float, training: bool):
+def block_prefixes(layer_sizes) -> List[str]:
+    """Residual blocks in execution order (their closing activation is named ``<prefix>.relu`` in tap / force)."""
+    out = []
+    for (stage, _, _, _), n in zip(STAGES, layer_sizes):
+        p = "res2plus1d." + stage
+        out += [p + ".block1"] + [f"{p}.blocks.{i}" for i in range(n - 1)]
+    return out
+
+
+def trunk_forward(x, sd, bufs, layer_sizes, alpha: float, training: bool, tap=None, force=None):
     """R2Plus1DNet.forward (R2Plus1D.py:217-226).  x: (B,3,T,H,W) fp32 -> (B,128)."""
     for u in stem_units(alpha):
-        x = run_unit(x, u, sd, bufs, training)
+        x = run_unit(x, u, sd, bufs, training, tap, force)
     for (stage, cin, cout, down), n in zip(STAGES, layer_sizes):
         p = "res2plus1d." + stage
-        x = res_block(x, p + ".block1", cin, cout, down, alpha, sd, bufs, training)
+        x = res_block(x, p + ".block1", cin, cout, down, alpha, sd, bufs, training, tap, force)
         for i in range(n - 1):
-            x = res_block(x, f"{p}.blocks.{i}", cout, cout, False, alpha, sd, bufs, training)
+            x = res_block(x, f"{p}.blocks.{i}", cout, cout, False, alpha, sd, bufs, training, tap, force)
     return x.mean(dim=(2, 3, 4))  # AdaptiveAvgPool3d(1) + view  (R2Plus1D.py:215,224-225)
 
 
@@ -121,9 +143,9 @@ def head_forward(f, sd, bufs, alpha: float, training: bool):
     return F.linear(h, sd["linear.3.weight"], sd["linear.3.bias"])
 
 
-def classifier_forward(x, sd, bufs, layer_sizes, alpha: float, training: bool = True):
+def classifier_forward(x, sd, bufs, layer_sizes, alpha: float, training: bool = True, tap=None, force=None):
     """R2Plus1DClassifier.forward (R2Plus1D.py:280-283)."""
-    return head_forward(trunk_forward(x, sd, bufs, layer_sizes, alpha, training), sd, bufs, alpha, training)
+    return head_forward(trunk_forward(x, sd, bufs, layer_sizes, alpha, training, tap, force), sd, bufs, alpha, training)
 
 
 def all_units(layer_sizes, alpha: float) -> List[ConvUnit]:

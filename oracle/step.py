@@ -45,10 +45,11 @@ def clip_grad_norm(grads: Sequence[torch.Tensor], max_norm: float) -> float:
 
 
 def r2plus1d_loss_and_grads(x, y, params: Dict[str, torch.Tensor], bufs, layer_sizes, alpha,
-                            loss: Callable[[torch.Tensor, torch.Tensor], torch.Tensor]):
-    """One forward+loss+backward of the oracle classifier.  Returns (logits, loss, grads dict)."""
+                            loss: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], tap=None, force=None):
+    """One forward+loss+backward of the oracle classifier.  Returns (logits, loss, grads dict).  tap / force: the
+    LeakyReLU diagnostics of r2plus1d._leaky."""
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
-    logits = r2plus1d.classifier_forward(x, leaves, bufs, layer_sizes, alpha, training=True)
+    logits = r2plus1d.classifier_forward(x, leaves, bufs, layer_sizes, alpha, training=True, tap=tap, force=force)
     L = loss(logits, y)
     L.backward()
     return logits.detach(), L.detach(), {k: v.grad for k, v in leaves.items()}

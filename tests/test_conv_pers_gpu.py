@@ -159,23 +159,21 @@ def test_fused_batchnorm_backward_reduction(case, accumulate, pers_grid):
 def test_trunk_with_persistent_kernels_against_the_oracle():
     """Whole R(2+1)D classifier, forward + loss + backward, on a clip large enough that the default plan picks the
     persistent kernels (and the fused reduction where it exists) for the 64x64-resolution units (448 boxes >= 2 x 128):
-    logits and loss within 1e-4 of the fp64 oracle; every parameter gradient within 1e-3 (relative L2) of the fp64 oracle,
-    or within 3x of what the fp32 CPU oracle itself achieves on that parameter (a few BatchNorm scale gradients are sums
-    with heavy cancellation: the fp32 CPU path is ~1e-2 off its own fp64 evaluation there)."""
+    logits and loss within 1e-4 of the fp64 oracle; every parameter gradient within 1e-3 (relative L2) of the fp64 oracle
+    evaluated on the activation pattern the HIP forward took (tests/kink_util.py: the sign flips against the oracle's own
+    pattern are listed and must be few and within rounding error of zero)."""
     from oracle import losses as ol, r2plus1d as orc, step as ostep
     from src.loss import FocalLoss
     from src.models.R2Plus1D import R2Plus1DClassifier
+    from tests import kink_util as ku
     layers, alpha = [1, 1, 1, 1], 0.01
     B, T, S, seed = 2, 7, 128, 5
     params, bufs = orc.synth_state(layers, seed, alpha)
     x = orc.synth_clip(B, T, S, seed); y = orc.synth_labels(B, seed)
-    w32 = torch.ones(2)
-    _, _, g32 = ostep.r2plus1d_loss_and_grads(x, y, params, bufs, layers, alpha, lambda o, t: ol.focal_loss(o, t, w32, 2.0))
-    params, bufs = orc.synth_state(layers, seed, alpha)
     p64 = {k: v.double() for k, v in params.items()}
     b64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in bufs.items()}
     w = torch.ones(2, dtype=torch.float64)
-    logits, loss, g64 = ostep.r2plus1d_loss_and_grads(x.double(), y, p64, b64, layers, alpha, lambda o, t: ol.focal_loss(o, t, w, 2.0))
+    logits, loss, _ = ostep.r2plus1d_loss_and_grads(x.double(), y, p64, b64, layers, alpha, lambda o, t: ol.focal_loss(o, t, w, 2.0))
     m = R2Plus1DClassifier(input_size=(3, T, S, S), num_classes=2, layer_sizes=layers, alpha=alpha)
     params, bufs = orc.synth_state(layers, seed, alpha)
     sd = dict(params); sd.update(bufs)
@@ -187,18 +185,15 @@ def test_trunk_with_persistent_kernels_against_the_oracle():
     torch.cuda.synchronize()
     assert relerr(lg.detach().cpu(), logits.detach()) < 1e-4
     assert abs(lossg.item() - float(loss)) < 1e-4 * max(1.0, abs(float(loss)))
-    gmax = max(float(v.norm()) for v in g64.values())
-    bad = []
-    for k, p in m.named_parameters():
-        if k == "linear.0.bias":          # feeds BatchNorm1d: its true gradient is zero, what is left is rounding noise
-            continue
-        r = g64[k]
-        den = max(float(r.norm()), 1e-6 * gmax)
-        e = float((p.grad.cpu().double() - r).norm() / den)
-        e32 = float((g32[k].double() - r).norm() / den)
-        if e > max(1e-3, 3.0 * e32):
-            bad.append((k, e, e32))
-    assert not bad, bad
+    rep = ku.gradient_report(m, x, y, layers, alpha, seed, torch.ones(2), 2.0, DEV)
+    for name, idx, vh, vo, rms in rep["flips"][:12]:
+        print(f"  sign flip: {name}[{idx}]  hip {vh:+.3e}  fp64 oracle {vo:+.3e}  (tensor rms {rms:.3e})")
+    print("gradients vs fp64 oracle: own pattern %.2e, HIP pattern worst %.2e (%s) median %.2e, flips %d" % (
+        rep["worst_own"], rep["worst_pattern"], rep["worst_name"], rep["median_pattern"], len(rep["flips"])))
+    assert len(rep["flips"]) <= rep["max_flips"], (len(rep["flips"]), rep["elements"])
+    for name, idx, vh, vo, rms in rep["flips"]:
+        assert abs(vh) <= 1e-4 * rms and abs(vo) <= 1e-4 * rms, (name, idx, vh, vo, rms)
+    assert rep["worst_pattern"] < 1e-3, rep
 
 
 SPLIT_CASES = [c for c in CASES if c[0] != "stem"] + [

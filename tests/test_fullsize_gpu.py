@@ -50,6 +50,8 @@ def test_fullsize_forward_backward(reference, exact):
         loss = loss_fn(logits, y.to(DEV))
         loss.backward()
         torch.cuda.synchronize()
+        from tests import kink_util as ku
+        rep = ku.gradient_report(model, x, y, LS, ALPHA, SEED, torch.ones(2), 2.0, DEV)      # (same arithmetic mode)
     finally:
         ops.set_exact_fp32(False)
     lerr = float((logits.detach().cpu() - ref_logits).abs().max() / ref_logits.abs().max())
@@ -72,10 +74,50 @@ def test_fullsize_forward_backward(reference, exact):
           f"{np.median(errs):.2e} worst {worst:.2e} ({worst_name}); vs fp32 oracle: median {np.median(errs32):.2e}; "
           f"fp32 oracle vs fp64 oracle: median {np.median(cpu_noise):.2e} worst {max(cpu_noise):.2e}")
 
-    # This workload is ill conditioned for gradients at B=4 (the head's BatchNorm1d sees 4 samples): the fp32 CPU
-    # oracle itself sits `cpu_noise` (~5e-3) away from its fp64 evaluation.  Hold the HIP path to the same order.
-    assert np.median(errs) < max(2e-3, 4.0 * float(np.median(cpu_noise))), (np.median(errs), np.median(cpu_noise))
-    assert worst < max(1e-2, 5.0 * max(cpu_noise)), (worst, max(cpu_noise))
+    # Gradients: the yardstick is the fp64 oracle evaluated on the activation pattern the HIP forward took
+    # (tests/kink_util.py); no multiple-of-the-CPU-noise allowance.
+    for name, idx, vh, vo, rms in rep["flips"][:12]:
+        print(f"  sign flip: {name}[{idx}]  hip {vh:+.3e}  fp64 oracle {vo:+.3e}  (tensor rms {rms:.3e})")
+    print("B=%d mode=%s: vs fp64 oracle on the HIP activation pattern: worst %.2e (%s), median %.2e; flips %d" % (
+        B, "exact" if exact else "split", rep["worst_pattern"], rep["worst_name"], rep["median_pattern"], len(rep["flips"])))
+    assert len(rep["flips"]) <= rep["max_flips"], (len(rep["flips"]), rep["elements"])
+    for name, idx, vh, vo, rms in rep["flips"]:
+        assert abs(vh) <= 1e-4 * rms and abs(vo) <= 1e-4 * rms, (name, idx, vh, vo, rms)
+    assert rep["worst_pattern"] < 1e-3, rep
+
+
+def test_headline_shape_b8_gradients_against_fp64_oracle():
+    """The shape bench.py times (B=8, T=21, 128x128, [1,2,2,1], default split arithmetic): logits / loss within 1e-3 of the
+    fp64 oracle, every parameter gradient within 1e-3 (median) / 3e-3 (worst, relative L2) of the fp64 oracle on the HIP
+    path's activation pattern; flips listed, few, and within rounding error of zero."""
+    from tests import kink_util as ku
+    torch.set_num_threads(16)
+    B8, seed = 8, 1234
+    params, bufs = orc.synth_state(LS, seed, ALPHA)
+    x = orc.synth_clip(B8, T, S, seed); y = orc.synth_labels(B8, seed)
+    model = R2Plus1DClassifier(input_size=(3, T, S, S), num_classes=2, layer_sizes=LS, alpha=ALPHA)
+    sd = dict(params); sd.update(bufs)
+    model.load_state_dict(sd, strict=True)
+    model.to(DEV).train()
+    logits = model(x.to(DEV))
+    loss = FocalLoss(weight=torch.ones(2), gamma=2.0)(logits, y.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    p64 = {k: v.double() for k, v in params.items()}
+    b64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in orc.synth_state(LS, seed, ALPHA)[1].items()}
+    w = torch.ones(2, dtype=torch.float64)
+    l64, L64, _ = ostep.r2plus1d_loss_and_grads(x.double(), y, p64, b64, LS, ALPHA, lambda o, t: ol.focal_loss(o, t, w, 2.0))
+    assert float((logits.detach().cpu().double() - l64).abs().max() / l64.abs().max()) < 1e-3
+    assert abs(loss.item() - float(L64)) < 1e-3 * max(1.0, abs(float(L64)))
+    rep = ku.gradient_report(model, x, y, LS, ALPHA, seed, torch.ones(2), 2.0, DEV)
+    for name, idx, vh, vo, rms in rep["flips"][:12]:
+        print(f"  sign flip: {name}[{idx}]  hip {vh:+.3e}  fp64 oracle {vo:+.3e}  (tensor rms {rms:.3e})")
+    print("B=8 headline shape: vs fp64 oracle own pattern %.2e; on the HIP activation pattern: worst %.2e (%s), median %.2e; flips %d" % (
+        rep["worst_own"], rep["worst_pattern"], rep["worst_name"], rep["median_pattern"], len(rep["flips"])))
+    assert len(rep["flips"]) <= rep["max_flips"], (len(rep["flips"]), rep["elements"])
+    for name, idx, vh, vo, rms in rep["flips"]:
+        assert abs(vh) <= 1e-4 * rms and abs(vo) <= 1e-4 * rms, (name, idx, vh, vo, rms)
+    assert rep["worst_pattern"] < 1e-3, rep
 
 
 def test_side_stream_schedule_is_bit_identical_to_serial():

@@ -62,24 +62,100 @@ def test_train_per_epoch_matches_reference_step_fixture(golden_dir, exact, fused
     assert np.array_equal(np.stack(preds), g["preds"])                 # bit-exact label bookkeeping
     assert ta == float(g["train_acc"])
     assert abs(tf - float(g["train_f1"])) < 1e-12
-    # epoch loss over a 3-step trajectory: after the first AdamW update the two runs no longer share parameters bit for
-    # bit (Adam turns round-off-level gradient differences into +-lr), so the default split arithmetic gets 5e-3 here;
-    # single-step loss parity at 1e-3 is asserted in test_model_gpu.py / test_fullsize_gpu.py
-    assert abs(tl - float(g["train_loss"])) < (1e-3 if exact else 5e-3) * max(1.0, abs(float(g["train_loss"])))
-    errs = []
+    # epoch loss over the 3-step trajectory (mean of the three step losses)
+    dloss = abs(tl - float(g["train_loss"])) / max(1.0, abs(float(g["train_loss"])))
+    print("epoch-loss deviation from the reference fixture: %.2e (%s)" % (dloss, "exact" if exact else "split"))
+    # Parameter deltas.  AdamW's first steps move every element by ~lr * sign(gradient): where a gradient element is at
+    # round-off level its sign -- and with it a full 2 lr -- depends on the last bits of ANY implementation (the
+    # reference's fp32 run included).  So the comparison is made where the gradient is resolved: elements whose first-step
+    # gradient (fp64 oracle) exceeds 1e-3 of their tensor's largest.  Those must agree with the reference's recorded
+    # deltas to 0.05 lr in both modes; the excluded share is reported and bounded.
+    from oracle import step as ostep
+    params, bufs = orc.synth_state(ls, seed, alpha)
+    p64 = {k: v.double() for k, v in params.items()}
+    b64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in bufs.items()}
+    w64 = torch.ones(2, dtype=torch.float64)
+    _, _, g64 = ostep.r2plus1d_loss_and_grads(batches[0][0].double(), batches[0][1], p64, b64, ls, alpha,
+                                              lambda o, t: ol.focal_loss(o, t, w64, 2.0))
+    errs, resolved = [], []
     for k, p in model.named_parameters():
-        if k == "linear.0.bias":        # Adam step of a round-off-noise gradient: sign-chaotic on both sides
+        if k == "linear.0.bias":        # feeds BatchNorm1d: its gradient is analytically zero, Adam's step of it pure noise
             continue
+        gs = np.abs(subsample(g64[k]))
+        resolved.append(gs > 1e-3 * float(g64[k].abs().max()))
         errs.append(np.abs(subsample(p.detach() - before[k]) - g["dsub/" + k]) / 2e-4)
-    errs = np.concatenate(errs)
-    print("parameter-delta error / lr: worst %.3f, fraction above 0.25: %.4f" % (errs.max(), float((errs > 0.25).mean())))
-    # Adam normalises gradients: every delta is ~ +-lr, and where a gradient element is round-off-sized its SIGN (so a
-    # full 2*lr) depends on the last bits.  Exact mode: none of the sampled elements is in that regime; split mode
-    # (1e-5-level gradient differences on this 4-sample fixture, one kink flip): a few per cent of them are.
+    errs = np.concatenate(errs); resolved = np.concatenate(resolved)
+    print("parameter-delta error / lr on resolved-gradient elements: worst %.3f median %.4f; unresolved share %.3f (their worst %.3f)" % (
+        errs[resolved].max(), float(np.median(errs[resolved])), 1.0 - float(resolved.mean()),
+        errs[~resolved].max() if (~resolved).any() else 0.0))
+    assert float(resolved.mean()) > 0.85
     if exact:
-        assert errs.max() < 0.25
+        # exact-fp32 arithmetic reproduces the reference's recorded 3-step trajectory itself
+        assert errs[resolved].max() < 0.05, float(errs[resolved].max())
+        assert dloss < 1e-3, dloss
     else:
-        assert float((errs > 0.25).mean()) < 0.10 and float(np.median(errs)) < 0.05
+        # The default split arithmetic lands one LeakyReLU input of this fixture on the other side of zero than the
+        # reference did (listed by test_split_mode_single_step_matches_oracle_on_its_activation_pattern below), which moves
+        # the first AdamW step of many elements by O(lr) and the following losses with it; the trajectory-level bars are the
+        # loose ones here, the step itself is held to the strict bar in that test.
+        assert dloss < 2e-3, dloss
+        assert float(np.median(errs[resolved])) < 0.05
+
+
+def test_split_mode_single_step_matches_oracle_on_its_activation_pattern(golden_dir):
+    """One optimisation step of train_per_epoch (default split arithmetic, clip 1.0, ClipAdamW 2e-4) on the first batch of the
+    step fixture: every parameter's delta against the fp64 oracle's step -- gradients evaluated on the activation pattern the
+    HIP forward took (tests/kink_util.py), then clip_grad_norm + AdamW in fp64 -- within 0.05 lr wherever the gradient is
+    resolved (> 1e-3 of its tensor's largest).  The sign flips against the oracle's own pattern are listed and must be
+    near-zero pre-activations."""
+    from oracle import step as ostep
+    from src.optim import ClipAdamW
+    from tests import kink_util as ku
+    g = np.load(os.path.join(golden_dir, "step_tiny.npz"))
+    ls = [int(v) for v in g["layer_sizes"]]
+    B, T, S, alpha, seed = int(g["B"]), int(g["T"]), int(g["S"]), float(g["alpha"]), int(g["seed"])
+    lr = 2e-4
+    model = _model(ls, T, S, alpha, seed)
+    x, y = orc.synth_clip(B, T, S, seed), orc.synth_labels(B, seed, 0.4)
+    model.train()
+    pre_hip, _ = ku.hip_preactivations(model, x.to(DEV))
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    opt = ClipAdamW(model.parameters(), lr=lr)
+    train_per_epoch([(x, y)], model, opt, None, FocalLoss(weight=torch.ones(2), gamma=2.0), DEV, 1.0, "single")
+    torch.cuda.synchronize()
+    w64 = torch.ones(2, dtype=torch.float64)
+    lossf = lambda o, t: ol.focal_loss(o, t, w64, 2.0)
+    params, bufs = orc.synth_state(ls, seed, alpha)
+    _, _, _, pre64 = ku.oracle_preactivations(x, y, params, bufs, ls, alpha, lossf)
+    fl = ku.flips(pre_hip, pre64)
+    for name, idx, vh, vo, rms in fl:
+        print(f"  sign flip: {name}[{idx}]  hip {vh:+.3e}  fp64 oracle {vo:+.3e}  (tensor rms {rms:.3e})")
+        assert abs(vh) <= 1e-4 * rms and abs(vo) <= 1e-4 * rms
+    assert len(fl) <= 8
+    params, bufs = orc.synth_state(ls, seed, alpha)
+    _, _, g64 = ku.oracle_grads_on_pattern(x, y, params, bufs, ls, alpha, lossf, ku.sign_masks(pre_hip))
+    # the reference's step (src/train.py:64-66) in fp64: clip_grad_norm_(1.0), AdamW(lr, betas (0.9, 0.999), eps 1e-8, wd 1e-2)
+    names = [k for k, _ in model.named_parameters()]
+    leaves = [params[k].double().clone().requires_grad_(True) for k in names]
+    for leaf, k in zip(leaves, names):
+        leaf.grad = g64[k].clone()
+    ostep.clip_grad_norm([l.grad for l in leaves], 1.0)
+    torch.optim.AdamW(leaves, lr=lr).step()
+    worst, excluded, total = 0.0, 0, 0
+    for leaf, k in zip(leaves, names):
+        if k == "linear.0.bias":
+            continue
+        d_ref = (leaf.detach() - params[k].double())
+        d_hip = (dict(model.named_parameters())[k].detach() - before[k]).cpu().double()
+        res = g64[k].abs() > 1e-3 * g64[k].abs().max()
+        total += res.numel(); excluded += int((~res).sum())
+        if res.any():
+            worst = max(worst, float(((d_hip - d_ref).abs()[res]).max()) / lr)
+    print("single step, split mode: worst delta error on resolved-gradient elements %.4f lr; unresolved share %.3f; flips %d" % (
+        worst, excluded / total, len(fl)))
+    assert excluded / total < 0.25
+    assert worst < 0.05, worst
+
 
 
 def test_valid_per_epoch_and_other_losses():

@@ -5,11 +5,14 @@ every kernel of this library is launched on torch's current stream, so stream ca
 optimizer step stays outside.  Requirements, as for any captured step: fixed input shapes, no host synchronisation inside
 the step, random masks only from torch's device generator (capture-aware); the NoiseLayer of the 0D encoders, which draws from
 the CPU generator as the reference does, is switched to a pinned staging buffer that is refilled before every replay.  Gradients live in static tensors that the graph overwrites on every replay.
-Observed on this stack (ROCm 7.2, torch 2.10): ending the capture segfaults inside the runtime when an output or loss tensor that
-still carries its grad_fn from an EARLIER EAGER step on the legacy default stream is alive during the capture (probed on the
-full-size SlowFast: one such step is enough; dropping the reference or ``.detach()``-ing it, or having run the eager step on any
-other stream, avoids it; reproducer: ``SF_GRAPH=1 SF_GRAPH_DEFAULT=1 python tools/slowfast_smoke.py 4``).  So: construct the
-GraphedStep first, or keep eager work under ``torch.cuda.stream(side)``, or detach / drop what earlier steps returned.
+One precondition comes from PyTorch's autograd, not from this library: no autograd graph of an EARLIER step may still be alive
+(a kept loss / output tensor is enough).  Such a graph keeps the parameters' AccumulateGrad nodes alive, and those nodes remember
+the stream they were created on; if that was the legacy default stream, the captured backward makes the capture stream
+synchronise with the default stream, which is illegal inside a capture -- PyTorch warns ("The AccumulateGrad node's stream does
+not match ... break CUDA graph capture if the AccumulateGrad node's stream is the default stream") and ROCm 7.2 then segfaults in
+hipStreamEndCapture instead of returning an error (probed with tools/graph_capture_probe.py: `keep` crashes in capture_end,
+`drop` captures and replays).  ``GraphedStep`` therefore runs its warm-up steps on a side stream while listening for exactly
+that warning and raises a RuntimeError that says what to delete, BEFORE anything is captured.
 """
 from typing import Callable, Sequence
 
@@ -28,13 +31,32 @@ class GraphedStep:
         self._done = torch.cuda.Event()
         self.inputs = [t.detach().clone() for t in example_inputs]
         self.target = example_target.detach().clone()
+        import warnings
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                      # warm-up off the default stream: builds plans, fills the allocator
-            for _ in range(warmup):
-                model.zero_grad(set_to_none=True)
-                self._eager()
+        warn_always = torch.is_warn_always_enabled()
+        torch.set_warn_always(True)                        # the autograd warning below is a warn-once: make it observable every time
+        try:
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                with torch.cuda.stream(side):              # warm-up off the default stream: builds plans, fills the allocator
+                    for _ in range(max(1, warmup)):
+                        model.zero_grad(set_to_none=True)
+                        self._eager()
+        finally:
+            torch.set_warn_always(warn_always)
         torch.cuda.current_stream().wait_stream(side)
+        stale = [w for w in caught if "AccumulateGrad node's stream does not match" in str(w.message)]
+        if stale:
+            for mod in self.noise_layers:
+                mod.__dict__.pop("_graph_mode", None)
+            raise RuntimeError(
+                "GraphedStep: an autograd graph from an earlier training step is still alive (a loss or output tensor that was not "
+                "deleted or detached keeps it): its AccumulateGrad nodes live on another stream, and a capture that synchronises "
+                "with the default stream is illegal (on ROCm 7.2 it segfaults in hipStreamEndCapture).  Delete or .detach() what "
+                "earlier steps returned, then construct GraphedStep again.")
+        for w in caught:                                   # anything else: pass on
+            warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
         model.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):

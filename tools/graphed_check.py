@@ -1,6 +1,6 @@
 """Whole-step HIP graph (src/utils/graphed.py) against the eager step: bit-identical loss and gradients for SlowFast (tiny) and
-ViViT (dropout 0), a replay with a new batch, and ViViT with dropout running.  Run in a fresh process: on this stack a capture
-after model steps on the legacy default stream crashes in the runtime, so everything eager here runs on a side stream.
+ViViT (dropout 0), a replay with a new batch, and ViViT with dropout running.  The eager reference steps run on a side stream and
+drop their autograd graphs (src/utils/graphed.py explains why no earlier graph may outlive into a capture).
     python tools/graphed_check.py        -> prints "graphed_check OK" """
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -13,11 +13,6 @@ m = SlowFast(input_shape=(3, 32, 224, 224), layers=[1, 2, 2, 1], alpha=4, tau_fa
 loss_fn = LDAMLoss(cls_num_list=[100, 2000], max_m=0.5, s=1.0, weight=None)
 x = torch.randn(B, 3, 32, 224, 224, device=dev) * 50
 y = (torch.arange(B) % 2).to(dev)
-# with SF_GRAPH the eager reference runs on a side stream: a HIP-graph capture after model steps on the legacy default stream
-# crashes in hipStreamEndCapture on this stack (see src/utils/graphed.py)
-_side = torch.cuda.Stream() if (os.environ.get('SF_GRAPH') and not os.environ.get('SF_GRAPH_DEFAULT')) else None
-if _side is not None:
-    _side.wait_stream(torch.cuda.current_stream()); torch.cuda.set_stream(_side)
 def step():
     m.zero_grad(set_to_none=True)
     out = m(x); loss = loss_fn(out, y); loss.backward(); return out, loss
@@ -44,7 +39,8 @@ if os.environ.get("SF_GRAPH"):
     from src.utils.graphed import GraphedStep
     out, loss = step(); torch.cuda.synchronize()
     eager = {k: p.grad.clone() for k, p in m.named_parameters()}; eager_loss = float(loss.detach())
-    torch.cuda.synchronize(); torch.cuda.set_stream(torch.cuda.default_stream())
+    del out, loss                                  # no autograd graph of an eager step may outlive into the capture (src/utils/graphed.py)
+    torch.cuda.synchronize()
     gs = GraphedStep(m, loss_fn, [x], y)
     o2, l2 = gs([x], y); torch.cuda.synchronize()
     same = all(torch.equal(eager[k], p.grad) for k, p in m.named_parameters())

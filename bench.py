@@ -132,7 +132,7 @@ def main():
 
     from src.models.R2Plus1D import R2Plus1DClassifier
     from src.loss import FocalLoss
-    from src.distributed import GradAllReducer, broadcast_module_state
+    from src.distributed import GradAllReducer, broadcast_module_state, dp_train_step
 
     torch.manual_seed(1234)
     model = R2Plus1DClassifier(input_size=(3, T, S, S), num_classes=2, layer_sizes=LAYERS, alpha=ALPHA).to(device)
@@ -152,12 +152,16 @@ def main():
 
     def step():
         nonlocal finite
+        if reducer is not None:
+            # N > 1: the function the data-parallel loop itself uses (src/distributed.py: stage-wise all-reduce of the trunk
+            # gradients during backward, one bucket for the rest + the collective finite flag, device-side skip; no host sync)
+            loss, _, ok = dp_train_step(model, reducer, opt, loss_fn, x, y, max_norm_grad=1.0)
+            finite = finite * ok.reshape(())
+            return
         opt.zero_grad(set_to_none=True)
         logits = model(x)
         loss = loss_fn(logits, y)
         loss.backward()
-        if reducer is not None:
-            reducer.reduce_rest()
         if args.torch_optimizer:
             torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
             opt.step()

@@ -62,7 +62,12 @@ __global__ __launch_bounds__(256) void k_opt_norm(const float* __restrict__ part
 // written back scaled (clip_grad_norm_ clips in place).
 __global__ __launch_bounds__(256) void k_opt_adamw(const OptTensor* __restrict__ tens, const OptChunk* __restrict__ chunks,
                                                    const float* __restrict__ norm_coef, float lr, float beta1, float beta2,
-                                                   float eps, float weight_decay, float step_size, float inv_bc2_sqrt) {
+                                                   float eps, float weight_decay, float step_size, float inv_bc2_sqrt,
+                                                   const float* __restrict__ ok_flag) {
+  // ok_flag (optional, device scalar): anything but exactly 1 skips the whole update -- parameters, moments and gradients stay
+  // as they are.  The data-parallel loop passes the rank-averaged "loss is finite" flag here, so the reference's
+  // `if not torch.isfinite(loss): continue` (src/train.py:56-58) is decided on the device, collectively, without a host sync.
+  if (ok_flag && *ok_flag != 1.f) return;
   const OptChunk c = chunks[blockIdx.x];
   const OptTensor tt = tens[c.tensor];
   const long long base = (long long)c.offset * OPT_CHUNK;
@@ -109,6 +114,20 @@ extern "C" int md_opt_grad_norm(const void* tensors, const void* chunks, int32_t
   return MD_OK;
 }
 
+extern "C" int md_opt_adamw_step_if(const void* tensors, const void* chunks, int32_t nchunks, const float* norm_coef, float lr,
+                                    float beta1, float beta2, float eps, float weight_decay, int64_t step, const float* ok_flag,
+                                    void* stream) {
+  if (!tensors || !chunks) return MD_ERR_NULL;
+  if (nchunks <= 0 || step < 1) return MD_ERR_BAD_SHAPE;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  MD_KLAUNCH(k_opt_adamw, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const OptTensor*)tensors,
+             (const OptChunk*)chunks, norm_coef, lr, beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt, ok_flag);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+
 extern "C" int md_opt_adamw_step(const void* tensors, const void* chunks, int32_t nchunks, const float* norm_coef, float lr,
                                  float beta1, float beta2, float eps, float weight_decay, int64_t step, void* stream) {
   if (!tensors || !chunks) return MD_ERR_NULL;
@@ -117,7 +136,8 @@ extern "C" int md_opt_adamw_step(const void* tensors, const void* chunks, int32_
   const float step_size = (float)((double)lr / bc1);
   const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
   MD_KLAUNCH(k_opt_adamw, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const OptTensor*)tensors,
-             (const OptChunk*)chunks, norm_coef, lr, beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt);
+             (const OptChunk*)chunks, norm_coef, lr, beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt,
+             (const float*)nullptr);
   MD_CHECK_LAUNCH();
   return MD_OK;
 }

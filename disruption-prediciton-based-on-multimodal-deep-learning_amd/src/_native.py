@@ -125,6 +125,7 @@ SIGNATURES = {
     "md_opt_chunk_elems": (C.c_int, []),
     "md_opt_grad_norm": (C.c_int, [_P, _P, _I32, _F, _P, _P, _P]),
     "md_opt_adamw_step": (C.c_int, [_P, _P, _I32, _P, _F, _F, _F, _F, _F, C.c_int64, _P]),
+    "md_opt_adamw_step_if": (C.c_int, [_P, _P, _I32, _P, _F, _F, _F, _F, _F, C.c_int64, _P, _P]),
 }
 
 ERRORS = {-1: "bad shape", -2: "unsupported", -3: "workspace", -4: "kernel launch failed", -5: "null pointer"}

@@ -10,9 +10,11 @@ Exchange design for RCCL over xGMI (point-to-point links, small latency-bound me
   * the trunk backward produces ONE flat fp32 gradient buffer (``_plan.TrunkFunction``); after the backward of each
     residual stage its weight slice is all-reduced (AVG) asynchronously on RCCL's stream while the earlier stages'
     backward kernels keep the compute stream busy -- 5 messages of 0.1-3 MB instead of 201 tiny ones;
-  * BatchNorm gammas/betas (one contiguous tail of the same buffer) and the head's gradients go in one final
-    message each; the non-finite-loss decision (reference src/train.py:56-58) is made collectively (MIN over a
-    1-element flag) so no rank skips an all-reduce the others wait in;
+  * BatchNorm gammas/betas (one contiguous tail of the same buffer) go in one message; every other gradient (head,
+    other encoders) lives in ONE pre-flattened bucket whose last element is the rank's "loss is finite" flag, so the
+    non-finite-loss decision (reference src/train.py:56-58) rides on that all-reduce: collective, decided on the device
+    (the optimizer kernel skips unless the averaged flag is exactly 1), and no rank skips a collective the others wait in;
+    the step contains no host synchronisation;
   * BatchNorm statistics stay per rank (the reference has no SyncBN); parameters and buffers are broadcast from
     rank 0 once.
 """
@@ -53,7 +55,11 @@ def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None) ->
 
 class GradAllReducer:
     """Averages gradients across ranks.  With an R(2+1)D trunk inside `module`, the trunk's weight gradients are
-    reduced stage by stage during backward (see module docstring); everything else after backward."""
+    reduced stage by stage during backward (see module docstring).  Every other parameter's gradient lives in ONE
+    pre-flattened bucket (``p.grad`` are views into it, so autograd accumulates straight into the bucket: no cat, no copy back)
+    whose last element carries the rank's "loss is finite" flag; one all-reduce(AVG) after backward averages the gradients and
+    -- since an average of 0/1 flags is exactly 1 only if every rank said 1 -- decides the reference's non-finite skip
+    (src/train.py:56-58) collectively and on the device."""
 
     def __init__(self, module: torch.nn.Module, group=None):
         self.module = module
@@ -61,7 +67,6 @@ class GradAllReducer:
         self.world = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
         self.pending: List = []
-        self._native_avg = True
         self.trunk = None
         self._trunk_param_ids = set()
         for m in module.modules():
@@ -73,14 +78,28 @@ class GradAllReducer:
                         self._trunk_param_ids.add(id(p))
                 break
         self._stage_slices = None
+        self.rest = [p for p in module.parameters() if p.requires_grad and id(p) not in self._trunk_param_ids]
+        dev = next(module.parameters()).device
+        n = sum(p.numel() for p in self.rest)
+        self.flat_rest = torch.zeros(n + 1, device=dev, dtype=torch.float32)      # [gradients .. | finite flag]
+        self.flag = self.flat_rest[n:]                                            # 1-element view
+        self._views, o = [], 0
+        for p in self.rest:
+            self._views.append(self.flat_rest[o:o + p.numel()].view_as(p)); o += p.numel()
+        # does the collective library average natively?  probed ONCE, synchronously (an asynchronous failure could not be caught)
+        self._native_avg = False
+        if self.backend == "nccl":
+            try:
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=group)
+                self._native_avg = bool(probe.item() == 1.0)
+            except Exception:
+                self._native_avg = False
 
     # -- helpers
     def _avg(self, t: torch.Tensor, async_op: bool):
-        if self.backend == "nccl" and self._native_avg:
-            try:
-                return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
-            except Exception:          # collective library without AVG: sum and scale instead
-                self._native_avg = False
+        if self._native_avg:
+            return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
         w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         if async_op:
             return (w, t)
@@ -92,6 +111,17 @@ class GradAllReducer:
             h[0].wait(); h[1].div_(self.world)
         elif h is not None:
             h.wait()
+
+    def zero_grad(self) -> None:
+        """Replaces optimizer.zero_grad() in the data-parallel step: trunk parameters get fresh gradient views from the
+        executor's flat buffer every backward (grad = None); every other parameter's .grad is (re)pointed at its slice of the
+        zeroed bucket."""
+        for p in self.module.parameters():
+            if id(p) in self._trunk_param_ids:
+                p.grad = None
+        self.flat_rest.zero_()
+        for p, v in zip(self.rest, self._views):
+            p.grad = v
 
     def _build_stage_slices(self, grads):
         """weight-gradient range (in floats) of each stage inside the flat buffer; stage of unit from the plan order."""
@@ -112,7 +142,7 @@ class GradAllReducer:
         self._w_end = o
         self._stage_slices = sl
 
-    # -- called from TrunkFunction.backward after the backward of stage `st` (4 .. 0); st == -1: drain
+    # -- called from TrunkFunction.backward after the backward of stage `st` (4 .. 0)
     def _segment_hook(self, st: int, flat: torch.Tensor, grads, stream=None) -> None:
         """`stream`: the stream that produces this stage's weight gradients when it is not the current one (the plan's
         side stream); the all-reduce is queued behind it."""
@@ -130,49 +160,69 @@ class GradAllReducer:
                 self._wait(h)
             self.pending = []
 
-    def reduce_rest(self) -> None:
-        """After loss.backward(): average every gradient the trunk hook did not cover (head, other encoders)."""
-        rest = [p.grad for p in self.module.parameters() if p.grad is not None and id(p) not in self._trunk_param_ids]
-        if not rest:
-            return
-        flat = torch.cat([g.reshape(-1) for g in rest])
-        self._avg(flat, async_op=False)
-        o = 0
-        for g in rest:
-            g.copy_(flat[o:o + g.numel()].view_as(g)); o += g.numel()
+    def reduce_rest(self, finite: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """After loss.backward(): ONE all-reduce over the pre-flattened bucket of every gradient the trunk hook does not cover
+        (head, other encoders) plus the finite flag (``finite``: this rank's 0/1 device scalar; default 1).  Returns the reduced
+        flag (device, 1 element): exactly 1.0 iff the loss was finite on every rank."""
+        for p, v in zip(self.rest, self._views):
+            if p.grad is None:                       # parameter took no part in this step: contributes zeros
+                continue
+            if p.grad.data_ptr() != v.data_ptr():    # someone replaced .grad (e.g. optimizer.zero_grad(set_to_none=True)): fold it in
+                v.copy_(p.grad); p.grad = v
+        if finite is None:
+            self.flag.fill_(1.0)
+        else:
+            self.flag.copy_(finite.reshape(1).to(torch.float32))
+        self._avg(self.flat_rest, async_op=False)
+        return self.flag.clone()                     # (the bucket is zeroed again by the next step's zero_grad)
 
 
 def all_ranks_finite(loss: torch.Tensor, group=None) -> bool:
-    """Collective form of the reference's `if not torch.isfinite(loss): continue` (src/train.py:56-58)."""
+    """Collective form of the reference's `if not torch.isfinite(loss): continue` (src/train.py:56-58) WITH a host
+    synchronisation; the data-parallel step uses the device-side flag of GradAllReducer.reduce_rest instead."""
     flag = torch.isfinite(loss.detach()).to(torch.float32).reshape(1)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
     return bool(flag.item() > 0)
 
 
 def dp_train_step(model, reducer: GradAllReducer, optimizer, loss_fn, data, target, max_norm_grad: Optional[float] = None):
-    """One synchronous data-parallel optimisation step; returns the local (detached) loss and logits."""
-    optimizer.zero_grad()
+    """One synchronous data-parallel optimisation step.  Returns (local detached loss, detached logits, ok) where ``ok`` is
+    the all-rank finite flag as a DEVICE tensor (1.0 = the step was applied on every rank; anything else = skipped on every
+    rank) -- nothing in here synchronises the host when the optimizer is src.optim.ClipAdamW.  Backward always runs (a rank
+    with a non-finite loss contributes garbage gradients that no rank applies), so no rank can skip a collective the others
+    wait in."""
+    reducer.zero_grad()
     output = model(data)
     loss = loss_fn(output, target)
-    if not all_ranks_finite(loss, reducer.group):
-        return loss.detach(), output.detach(), False
+    finite = torch.isfinite(loss.detach()).to(torch.float32)
     loss.backward()
-    reducer.reduce_rest()
-    if getattr(optimizer, "fused_clip", False):             # src.optim.ClipAdamW: clip + update in one pass
-        optimizer.step(max_norm=max_norm_grad)
+    ok = reducer.reduce_rest(finite)
+    if getattr(optimizer, "fused_clip", False):             # src.optim.ClipAdamW: clip + update in one pass, device-side skip
+        optimizer.step(max_norm=max_norm_grad, ok=ok)
     else:
-        if max_norm_grad:
-            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm_grad)
-        optimizer.step()
-    return loss.detach(), output.detach(), True
+        if bool(ok.item() == 1.0):                          # torch optimizers: host decision (one sync per step)
+            if max_norm_grad:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm_grad)
+            optimizer.step()
+    return loss.detach(), output.detach(), ok
+
+
+def _per_sample(loss: torch.Tensor, loss_fn, n: int) -> torch.Tensor:
+    """Loss per sample for the epoch bookkeeping: the package's Focal / CE losses SUM over the batch, LDAM and torch's default
+    criteria average (src/loss.py:28,69,81 -- SURVEY Q3)."""
+    reduction = getattr(loss_fn, "reduction", None)
+    if reduction is None:
+        reduction = "mean" if type(loss_fn).__name__ == "LDAMLoss" else ("sum" if type(loss_fn).__name__ in ("FocalLoss", "CELoss") else "mean")
+    return loss / n if reduction == "sum" else loss
 
 
 def train_epoch_per_procs(rank: int, world_size: int, batch_size: Optional[int], model: torch.nn.Module,
                           train_dataset: Dataset, valid_dataset: Dataset, random_seed: int = 42, resume: bool = True,
                           loss_fn=None, model_filepath: str = "./weights/distributed.pt", optimizer=None, scheduler=None,
                           reducer: Optional[GradAllReducer] = None, epoch: int = 0):
-    """One epoch on this rank (reference :29-111).  Returns (train_loss, train_acc, valid_loss, valid_acc), the loss
-    averaged over batches and then over ranks."""
+    """One epoch on this rank (reference :29-111).  Returns (train_loss, train_acc, valid_loss, valid_acc): per-sample loss
+    and accuracy averaged over the batches of every rank.  Rank r sees samples r::world of the epoch's permutation
+    (DistributedSampler with set_epoch, which the reference forgot -- SURVEY Q2)."""
     device = torch.device("cuda:{}".format(rank)) if torch.cuda.is_available() else torch.device("cpu")
     if loss_fn is None:
         from .loss import CELoss
@@ -184,10 +234,10 @@ def train_epoch_per_procs(rank: int, world_size: int, batch_size: Optional[int],
     for data, target in train_loader:
         data, target = data.to(device), target.to(device)
         loss, output, ok = dp_train_step(model, reducer, optimizer, loss_fn, data, target)
-        if not ok:
-            continue
+        use = (ok.reshape(()) == 1.0).to(torch.float32)      # skipped batches do not count (device-side, no sync)
         pred = output.argmax(1)
-        agg[0] += loss / data.size(0); agg[1] += (pred == target).float().mean(); agg[2] += 1
+        agg[0] += torch.nan_to_num(_per_sample(loss, loss_fn, data.size(0))) * use
+        agg[1] += (pred == target).float().mean() * use; agg[2] += use
     if scheduler:
         scheduler.step()
     model.eval()
@@ -197,7 +247,7 @@ def train_epoch_per_procs(rank: int, world_size: int, batch_size: Optional[int],
             data, target = data.to(device), target.to(device)
             output = model(data)
             loss = loss_fn(output, target)
-            vag[0] += loss / data.size(0); vag[1] += (output.argmax(1) == target).float().mean(); vag[2] += 1
+            vag[0] += _per_sample(loss, loss_fn, data.size(0)); vag[1] += (output.argmax(1) == target).float().mean(); vag[2] += 1
     dist.all_reduce(agg); dist.all_reduce(vag)
     n, vn = max(float(agg[2]), 1.0), max(float(vag[2]), 1.0)
     return float(agg[0]) / n, float(agg[1]) / n, float(vag[0]) / vn, float(vag[1]) / vn
@@ -222,7 +272,11 @@ def train_per_proc(rank: int, world_size: int, batch_size: Optional[int], model:
         model.load_state_dict(torch.load(model_filepath, map_location=device, weights_only=True), strict=False)
     broadcast_module_state(model, 0)
     reducer = GradAllReducer(model)
-    optimizer = torch.optim.AdamW(model.parameters(), lr=2e-4)
+    if use_gpu:
+        from .optim import ClipAdamW                         # AdamW(lr 2e-4) of reference :51, with the device-side skip
+        optimizer = ClipAdamW(model.parameters(), lr=2e-4)
+    else:
+        optimizer = torch.optim.AdamW(model.parameters(), lr=2e-4)
     scheduler = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(optimizer, T_0=8, T_mult=2)
     hist = {k: [] for k in ("train_loss", "train_acc", "valid_loss", "valid_acc")}
     best = float("inf")
@@ -235,8 +289,9 @@ def train_per_proc(rank: int, world_size: int, batch_size: Optional[int], model:
                 hist[k].append(v)
             if verbose and epoch % verbose == 0:
                 print(f"epoch {epoch + 1}: train loss {tl:.3f} acc {ta:.3f} | valid loss {vl:.3f} acc {va:.3f}")
-            os.makedirs(os.path.dirname(model_filepath) or ".", exist_ok=True)
-            torch.save(model.state_dict(), model_filepath)
+            if not save_best_only:               # the per-epoch "last" checkpoint (reference :166-178)
+                os.makedirs(os.path.dirname(model_filepath) or ".", exist_ok=True)
+                torch.save(model.state_dict(), model_filepath)
             if vl < best:
                 best = vl
                 os.makedirs(os.path.dirname(save_best_dir) or ".", exist_ok=True)

@@ -36,6 +36,7 @@ class ClipAdamW(torch.optim.Optimizer):
         self.max_norm = max_norm
         self.last_grad_norm: Optional[torch.Tensor] = None      # device scalar of the most recent step (no host sync)
         self._cache = {}                                         # group index -> tables (see _tables)
+        self._pending_ok = []                                    # (flag, event, params) of steps issued with ok= (see _settle_skips)
 
     # ------------------------------------------------------------------ tables
     _RING = 4      # pinned staging buffers per group: the host may run this many table refreshes ahead of the device
@@ -107,8 +108,31 @@ class ClipAdamW(torch.optim.Optimizer):
             self._cache.clear()
 
     # ------------------------------------------------------------------ step
+    def _settle_skips(self, block: bool = False) -> None:
+        """Steps issued with ``ok=`` advance the host-side step counters optimistically; once the device flag of such a step is
+        known (its event has completed -- never waited for inside the training loop) and says "skipped", the counters are taken
+        back.  Until then the bias correction of the next step is one count ahead: exceptional path only (non-finite loss)."""
+        keep = []
+        for flag, ev, params in self._pending_ok:
+            if block:
+                ev.synchronize()
+            if ev.query():
+                if float(flag.item()) != 1.0:
+                    for p in params:
+                        self.state[p]["step"] = max(0, int(self.state[p]["step"]) - 1)
+            else:
+                keep.append((flag, ev, params))
+        self._pending_ok = keep
+
+    def state_dict(self):
+        self._settle_skips(block=True)
+        return super().state_dict()
+
     @torch.no_grad()
-    def step(self, closure=None, max_norm: Optional[float] = None):
+    def step(self, closure=None, max_norm: Optional[float] = None, ok: Optional[torch.Tensor] = None):
+        """``ok`` (optional device scalar, float32): the update is applied only if it equals 1 (see md_opt_adamw_step_if)."""
+        if self._pending_ok:
+            self._settle_skips()
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -148,8 +172,12 @@ class ClipAdamW(torch.optim.Optimizer):
             for p in sub:
                 self.state[p]["step"] = st_count + 1
             b1, b2 = group["betas"]
-            N.check(L.md_opt_adamw_step(C.c_void_p(tb["tens"].data_ptr()), C.c_void_p(tb["chunks"].data_ptr()), tb["nch"], coef,
-                                        float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                                        float(group["weight_decay"]), int(st_count + 1), stream), "md_opt_adamw_step")
+            N.check(L.md_opt_adamw_step_if(C.c_void_p(tb["tens"].data_ptr()), C.c_void_p(tb["chunks"].data_ptr()), tb["nch"], coef,
+                                           float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                           float(group["weight_decay"]), int(st_count + 1),
+                                           None if ok is None else C.c_void_p(ok.data_ptr()), stream), "md_opt_adamw_step_if")
             group["step"] = max(int(group.get("step", 0)), st_count + 1)
+        if ok is not None and work:
+            ev = torch.cuda.Event(); ev.record()
+            self._pending_ok.append((ok, ev, [p for _, _, _, sub in work for p in sub]))
         return loss

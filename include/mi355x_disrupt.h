@@ -329,6 +329,12 @@ int md_opt_grad_norm(const void* tensors, const void* chunks, int32_t nchunks, f
  * gradients are first scaled by norm_coef[1] in place, as clip_grad_norm_ does. */
 int md_opt_adamw_step(const void* tensors, const void* chunks, int32_t nchunks, const float* norm_coef, float lr,
                       float beta1, float beta2, float eps, float weight_decay, int64_t step, void* stream);
+/* Same update, applied only if the device scalar *ok_flag is exactly 1 (NULL: always).  The data-parallel loop passes the
+ * all-reduced (AVG) "loss is finite on this rank" flag: the reference's per-batch skip (src/train.py:56-58) becomes a collective,
+ * device-side decision with no host synchronisation in the step. */
+int md_opt_adamw_step_if(const void* tensors, const void* chunks, int32_t nchunks, const float* norm_coef, float lr,
+                         float beta1, float beta2, float eps, float weight_decay, int64_t step, const float* ok_flag,
+                         void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Whole-trunk executor: R2Plus1DNet.forward / backward (R2Plus1D.py:207-226) as one plan.

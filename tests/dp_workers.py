@@ -96,6 +96,7 @@ def cpu_worker(rank, world, port, out_dir):
     local = [p.grad.clone() for p in model.parameters()]
     model[0].grad_segment_hook = red._segment_hook
     loss, out, ok = dp_train_step(model, red, opt, loss_fn, x, y, max_norm_grad=None)
+    ok = bool(ok.item() == 1.0)
     reduced = [p.grad.clone() for p in model.parameters()]
     finite_all = all_ranks_finite(torch.tensor(float("nan") if rank == 1 else 1.0))
     torch.save({"local": local, "reduced": reduced, "params": [p.detach().clone() for p in model.parameters()],
@@ -138,3 +139,54 @@ def gpu_worker(rank, world, port, out_dir):
     torch.save({"local": local, "reduced": reduced}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
+
+
+class LoggedDataset(torch.utils.data.Dataset):
+    """(x, y) pairs whose accesses are logged per process; sample `nan_index` is all-NaN (a non-finite loss on whichever rank
+    draws it)."""
+
+    def __init__(self, n, nan_index=-1, seed=0):
+        g = torch.Generator().manual_seed(seed)
+        self.x = torch.randn(n, 6, generator=g)
+        self.y = (self.x[:, 0] + 0.3 * self.x[:, 1] > 0).long()
+        if nan_index >= 0:
+            self.x[nan_index] = float("nan")
+        self.log = []
+
+    def __len__(self):
+        return self.x.shape[0]
+
+    def __getitem__(self, i):
+        self.log.append(int(i))
+        return self.x[i], self.y[i]
+
+
+def loop_worker(rank, world, port, out_dir):
+    """src.distributed.train_per_proc end to end over gloo (CPU): the epoch loop, the rank partition, the rank-0 checkpoints,
+    the collective non-finite skip.  The model is a plain torch module (the loop is model-agnostic; the GPU trunk's own
+    exchange is covered by gpu_worker)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    from src import distributed as D
+    torch.manual_seed(1000 + rank)                          # different init per rank: the broadcast must fix it
+    model = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.Tanh(), torch.nn.Linear(8, 2))
+    train = LoggedDataset(24, nan_index=5, seed=1); valid = LoggedDataset(8, seed=2)
+    # snapshots of the parameters after every optimisation step (hook on the optimizer the loop creates)
+    snaps = []
+    orig_adamw = torch.optim.AdamW
+
+    class Spy(orig_adamw):
+        def step(self, *a, **k):
+            r = super().step(*a, **k)
+            snaps.append([p.detach().clone() for g in self.param_groups for p in g["params"]])
+            return r
+
+    torch.optim.AdamW = Spy
+    try:
+        hist = D.train_per_proc(rank, world, 4, model, train, valid, random_seed=7, resume=False,
+                                loss_fn=torch.nn.CrossEntropyLoss(reduction="sum"),
+                                model_filepath=os.path.join(out_dir, "last.pt"), num_epoch=3, verbose=None,
+                                save_best_only=False, save_best_dir=os.path.join(out_dir, "best.pt"))
+    finally:
+        torch.optim.AdamW = orig_adamw
+    torch.save({"hist": hist, "train_log": train.log, "valid_log": valid.log, "steps": len(snaps),
+                "params": [p.detach().clone() for p in model.parameters()]}, os.path.join(out_dir, f"loop_rank{rank}.pt"))

@@ -30,3 +30,35 @@ def test_grad_allreduce_world2_gloo():
     for p0, p1 in zip(r0["params"], r1["params"]):
         assert torch.equal(p0, p1)                       # broadcast + identical update keep replicas in sync
     assert r0["finite_all"] is False and r1["finite_all"] is False      # one NaN rank stops every rank
+
+
+def test_train_per_proc_end_to_end_world2_gloo():
+    """The mirrored entry points of the reference's src/distributed.py:29-213 actually run: two ranks, three epochs, batch 4 over
+    24 training samples.  Checked: rank r sees samples r::2 of each epoch's permutation (disjoint, complete, reshuffled by
+    set_epoch), the batch containing the NaN sample is skipped by BOTH ranks (same number of optimizer steps, replicas stay
+    bit-identical), rank 0 writes loadable last / best checkpoints, and rank 0 returns the history."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(dp_workers.loop_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        r0 = torch.load(os.path.join(d, "loop_rank0.pt"), weights_only=True)
+        r1 = torch.load(os.path.join(d, "loop_rank1.pt"), weights_only=True)
+        last = torch.load(os.path.join(d, "last.pt"), weights_only=True)
+        best = torch.load(os.path.join(d, "best.pt"), weights_only=True)
+    n, per_epoch = 24, 12
+    assert len(r0["train_log"]) == len(r1["train_log"]) == 3 * per_epoch
+    orders = []
+    for e in range(3):
+        a = r0["train_log"][e * per_epoch:(e + 1) * per_epoch]; b = r1["train_log"][e * per_epoch:(e + 1) * per_epoch]
+        assert not set(a) & set(b) and sorted(a + b) == list(range(n))           # disjoint and complete
+        g = torch.Generator().manual_seed(e)                                     # DistributedSampler: seed 0 + epoch
+        perm = torch.randperm(n, generator=g).tolist()
+        assert a == perm[0::2] and b == perm[1::2]                               # rank r takes r::W of the permutation
+        orders.append(a)
+    assert orders[0] != orders[1] != orders[2]                                   # set_epoch reshuffles
+    # 3 batches per epoch per rank; exactly one of the 9 steps meets the NaN sample on ONE rank per epoch -> both ranks skip it
+    assert r0["steps"] == r1["steps"] == 9 - 3
+    for p0, p1 in zip(r0["params"], r1["params"]):
+        assert torch.equal(p0, p1) and bool(torch.isfinite(p0).all())
+    assert set(last) == set(best) and all(torch.equal(last[k], p) for k, p in zip(last, r0["params"]))
+    h = r0["hist"]
+    assert all(len(h[k]) == 3 for k in ("train_loss", "train_acc", "valid_loss", "valid_acc"))
+    assert all(v == v and v < 10 for v in h["train_loss"] + h["valid_loss"])     # finite per-sample losses

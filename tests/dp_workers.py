@@ -136,7 +136,28 @@ def gpu_worker(rank, world, port, out_dir):
     dp_train_step(model, red, opt, loss_fn, x, y, max_norm_grad=None)
     torch.cuda.synchronize()
     reduced = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
-    torch.save({"local": local, "reduced": reduced}, os.path.join(out_dir, f"rank{rank}.pt"))
+    # ---- the sync-free step with src.optim.ClipAdamW: a batch whose loss is non-finite on ONE rank is skipped on BOTH
+    # (device-side flag inside the gradient bucket, md_opt_adamw_step_if), the next batch is applied on both
+    from src.optim import ClipAdamW
+    model.load_state_dict(sd0)
+    copt = ClipAdamW(model.parameters(), lr=1e-3)
+    before = [p.detach().clone() for p in model.parameters()]
+    xbad = x.clone()
+    if rank == 1:
+        xbad[0, 0, 0, 0, 0] = float("nan")
+    _, _, ok_bad = dp_train_step(model, red, copt, loss_fn, xbad, y, max_norm_grad=1.0)
+    torch.cuda.synchronize()
+    skipped_unchanged = all(torch.equal(a, p.detach()) for a, p in zip(before, model.parameters()))
+    model.load_state_dict(sd0)                  # (BatchNorm running statistics saw the NaN on rank 1: restore)
+    _, _, ok_good = dp_train_step(model, red, copt, loss_fn, x, y, max_norm_grad=1.0)
+    torch.cuda.synchronize()
+    after = [p.detach().cpu().clone() for p in model.parameters()]
+    changed = sum(0 if torch.equal(a.cpu(), p) else 1 for a, p in zip(before, after))
+    sd = copt.state_dict()                      # settles the pending flags: the skipped step does not count
+    steps = sorted({int(st["step"]) for st in sd["state"].values()})
+    torch.save({"local": local, "reduced": reduced, "ok_bad": float(ok_bad.item()), "ok_good": float(ok_good.item()),
+                "skipped_unchanged": skipped_unchanged, "changed": changed, "after": after, "steps": steps},
+               os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 

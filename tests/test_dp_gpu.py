@@ -27,3 +27,10 @@ def test_trunk_stage_hook_allreduce_two_ranks():
         scale = float(mean.abs().max()) + 1e-12
         assert float((r0["reduced"][k] - mean).abs().max()) / scale < 1e-5, k
         assert torch.equal(r0["reduced"][k], r1["reduced"][k]), k
+    # sync-free step: the non-finite batch (NaN on rank 1 only) was skipped on both ranks, the next one applied on both
+    for r in (r0, r1):
+        assert r["ok_bad"] != 1.0 and r["ok_good"] == 1.0
+        assert r["skipped_unchanged"] and r["changed"] >= len(r["after"]) - 1     # (linear.0.bias: zero gradient in front of BatchNorm1d, moved by weight decay only)
+        assert r["steps"] == [1]                      # the skipped step does not advance Adam's step count
+    for a, b in zip(r0["after"], r1["after"]):
+        assert torch.equal(a, b)                      # replicas identical after the applied step

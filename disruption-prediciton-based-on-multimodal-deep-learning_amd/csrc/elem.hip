@@ -511,3 +511,41 @@ extern "C" int md_clip_preprocess(const uint8_t* frames, int32_t B, int32_t T, i
   MD_CHECK_LAUNCH();
   return MD_OK;
 }
+
+
+// ---------------------------------------------------------------- class-balanced re-sampling (ImbalancedDatasetSampler)
+// torch.multinomial(weights, n, replacement=True) on the CPU (the reference's sampler, src/utils/sampler.py:29-32) is: cumulative
+// distribution of the normalised weights, then for each draw a uniform double u and the LEFTMOST category whose cumulative
+// probability is >= u (aten/src/ATen/native/cpu/MultinomialKernel.cpp).  The uniforms are a serial Mersenne-twister stream and
+// stay on the host generator; the search -- the O(n log C) part -- runs here, and only over this rank's share of the stream:
+// rank r of W takes draws r, r + W, ... (DistributedSampler's partition applied to the resampled index stream).
+// out[k] = index_map[search(u[rank + k * world])]   (index_map optional: the sampler's `indices` list)
+__global__ __launch_bounds__(256) void k_multinomial_shard(const double* __restrict__ cum, int64_t ncat, const double* __restrict__ u,
+                                                           int64_t nsamples, int rank, int world, const int64_t* __restrict__ index_map,
+                                                           int64_t* __restrict__ out, int64_t nout) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nout) return;
+  const double x = u[rank + k * (int64_t)world];
+  int64_t left = 0, right = ncat;
+  while (right - left > 0) {
+    const int64_t mid = left + (right - left) / 2;
+    if (cum[mid] < x) left = mid + 1; else right = mid;
+  }
+  if (left >= ncat) left = ncat - 1;               // (cum[ncat-1] == 1 >= u always; guard against a malformed table)
+  out[k] = index_map ? index_map[left] : left;
+}
+extern "C" int64_t md_multinomial_shard_count(int64_t nsamples, int32_t rank, int32_t world) {
+  if (nsamples <= 0 || world <= 0 || rank < 0 || rank >= world || rank >= nsamples) return 0;
+  return (nsamples - rank + world - 1) / world;
+}
+extern "C" int md_multinomial_shard(const double* cum_dist, int64_t ncat, const double* uniforms, int64_t nsamples, int32_t rank,
+                                    int32_t world, const int64_t* index_map, int64_t* out, void* stream) {
+  if (!cum_dist || !uniforms || !out) return MD_ERR_NULL;
+  if (ncat <= 0 || nsamples <= 0 || world <= 0 || rank < 0 || rank >= world) return MD_ERR_BAD_SHAPE;
+  const int64_t nout = md_multinomial_shard_count(nsamples, rank, world);
+  if (nout == 0) return MD_OK;
+  MD_KLAUNCH(k_multinomial_shard, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cum_dist, ncat, uniforms,
+             nsamples, rank, world, index_map, out, nout);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}

@@ -287,6 +287,16 @@ int md_gelu(const float* x, const float* dy, int32_t kind, int64_t n, float* out
  * layout 1: out [B][T][S][S][4] with channel 3 = 0 (the kernels' channels-last layout).  Exact: uint8 -> fp32 minus the mean. */
 int md_clip_preprocess(const uint8_t* frames, int32_t B, int32_t T, int32_t Hr, int32_t Wr, int32_t S, const float* mean_bgr,
                        int32_t layout, float* out, void* stream);
+
+/* Class-balanced re-sampling as a device-side, rank-sharded index stream (ImbalancedDatasetSampler, src/utils/sampler.py:5-35:
+ * torch.multinomial with replacement over 1 / class-count weights).  cum_dist: the normalised cumulative distribution in
+ * float64 (cum_dist[ncat-1] == 1), uniforms: nsamples float64 draws of the SAME CPU generator stream torch.multinomial would
+ * consume; rank r of `world` receives draws r, r + world, ...: out[k] = index_map[leftmost c with cum_dist[c] >= u[r + k*world]]
+ * (index_map may be NULL).  Index-exact with torch.multinomial for the same generator state.  md_multinomial_shard_count
+ * gives the number of indices rank r receives. */
+int64_t md_multinomial_shard_count(int64_t nsamples, int32_t rank, int32_t world);
+int md_multinomial_shard(const double* cum_dist, int64_t ncat, const double* uniforms, int64_t nsamples, int32_t rank,
+                         int32_t world, const int64_t* index_map, int64_t* out, void* stream);
 /* Tensor fusion of TFN / TFN_GB (src/models/MultiModal.py:214-220, 301-307): out [B][(Da+1)*(Dc+1)] = [1 | a[b]] (x) [1 | c[b]]
  * (what the reference builds with torch.cat of ones + torch.bmm); the backward returns da [B][Da], dc [B][Dc]. */
 int md_outer_fwd(const float* a, const float* c, int32_t B, int32_t Da, int32_t Dc, float* out, void* stream);

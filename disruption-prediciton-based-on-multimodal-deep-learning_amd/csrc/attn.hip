@@ -3,6 +3,8 @@
 // forms the reference uses.  Sequences are tiny (S = 21 tokens, d_model 128-256, head dim 16-32): one workgroup per row /
 // per (batch, head); everything fixed-order fp32.
 #include "common.h"
+#include <map>
+#include <mutex>
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -473,14 +475,22 @@ static bool attn_use_mfma(const float* mask, const float* drop, int S, int D, in
   const int dh = D / H;
   return !off && !mask && !drop && S <= 16 * AT_MAXT && (dh == 16 || dh == 32 || dh == 64) && D % 4 == 0;
 }
-static bool attn_mfma_prepare() {        // raise the dynamic LDS limit of the attention kernels once
-  static const bool ok = [] {
+static bool attn_mfma_prepare() {        // raise the dynamic LDS limit of the attention kernels, once per device
+  static std::mutex mu;
+  static std::map<int, bool> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = done.find(dev);
+  if (it != done.end()) return it->second;
+  const bool ok = [] {
     bool good = true;
     auto set = [&](const void* f) { good = good && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; };
     set((const void*)k_attn_mfma_fwd<16>); set((const void*)k_attn_mfma_fwd<32>); set((const void*)k_attn_mfma_fwd<64>);
     set((const void*)k_attn_mfma_bwd_q<16>); set((const void*)k_attn_mfma_bwd_q<32>); set((const void*)k_attn_mfma_bwd_q<64>);
     return good;
   }();
+  done[dev] = ok;
   return ok;
 }
 static int attn_pp(int S) { return ((S + 15) & ~15) + 8; }       // pitch of the per-wave P buffer: = 8 (mod 16) floats
@@ -639,12 +649,15 @@ extern "C" int md_attention_bwd(const float* qkv, const float* probs, const floa
     switch (D / H) {
       case 16:
         MD_KLAUNCH(k_attn_mfma_bwd_q<16>, grid, dim3(256), la, s, qkv, probs, dout, S, B, D, H, bf, scale, pp, ds_scratch, dqkv);
+        MD_CHECK_LAUNCH();
         MD_KLAUNCH(k_attn_mfma_bwd_kv<16>, grid, dim3(256), lb, s, qkv, probs, dout, dsc, S, B, D, H, bf, dqkv); break;
       case 32:
         MD_KLAUNCH(k_attn_mfma_bwd_q<32>, grid, dim3(256), la, s, qkv, probs, dout, S, B, D, H, bf, scale, pp, ds_scratch, dqkv);
+        MD_CHECK_LAUNCH();
         MD_KLAUNCH(k_attn_mfma_bwd_kv<32>, grid, dim3(256), lb, s, qkv, probs, dout, dsc, S, B, D, H, bf, dqkv); break;
       default:
         MD_KLAUNCH(k_attn_mfma_bwd_q<64>, grid, dim3(256), la, s, qkv, probs, dout, S, B, D, H, bf, scale, pp, ds_scratch, dqkv);
+        MD_CHECK_LAUNCH();
         MD_KLAUNCH(k_attn_mfma_bwd_kv<64>, grid, dim3(256), lb, s, qkv, probs, dout, dsc, S, B, D, H, bf, dqkv); break;
     }
     MD_CHECK_LAUNCH();

@@ -172,7 +172,7 @@ def test_gb_loops_run_with_the_fused_optimizer_and_loss_on_gpu(golden_dir, tmp_p
     mk = lambda: FocalLoss(weight=torch.tensor([1.0, 2.0], device="cuda:0"), gamma=2.0)
     last = str(tmp_path / "last.pt")
     torch.save(m.state_dict(), last)
-    w = GB_estimate(1, tr, va, last, m, opt, None, mk(), "cuda:0", 1.0)
+    w = GB_estimate(2, tr, va, last, m, opt, None, mk(), "cuda:0", 1.0)
     assert abs(sum(w.values()) - 1.0) < 1e-9
     loss_gb = GradientBlending(mk(), mk(), mk(), 0.2, 0.3, 0.5, 1.0)
     hist = train_GB_dynamic(tr, va, m, opt, None, loss_gb, mk(), "cuda:0", num_epoch=1, verbose=None,

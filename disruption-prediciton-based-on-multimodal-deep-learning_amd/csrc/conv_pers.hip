@@ -77,6 +77,7 @@ __global__ __launch_bounds__(512) void k_conv_pers(
     }
     sK[q] = ko;
   }
+  if (t < 32) ((int*)(sm + pg.off_sync))[t] = 0;
   if (t < PM) {
     const int rt = mdiv(t, g.m_byx); const int r = t - rt * g.byx;
     const int ry = mdiv(r, g.m_bx); const int rx = r - ry * g.bx;
@@ -227,120 +228,160 @@ __global__ __launch_bounds__(512) void k_conv_pers(
   if (cur < pg.nboxes) { issue(cur); commit(); }
   __syncthreads();                                                     // both teams' first patches complete
 
-  for (int s = 0; s < 2 * niter + 1; ++s) {
-    const int ph = s - team;                                           // team 1 runs one phase behind team 0
-    if (ph >= 0 && ph < 2 * niter) {
-      if ((ph & 1) == 0) {
-        // ================= MATRIX phase of box `cur`
-        const int nxt = cur + stride;
-        if (nxt < pg.nboxes && !(dbg & 16)) issue(nxt);                // in flight during the matrix loop
-        if (cur < pg.nboxes && !(dbg & 64)) {
-          // destination pixels of this box (byte offsets of channel c0; pixels outside the tensor: out-of-range offset)
-          {
-            int b = cur;
-            const int q1 = mdiv(b, pg.m_nbx); const int xb = b - q1 * g.nbx; b = q1;
-            const int q2 = mdiv(b, pg.m_nby); const int yb = b - q2 * g.nby; b = q2;
-            const int n = mdiv(b, pg.m_nbt); const int tb = b - n * g.nbt;
-            const int t0 = tb * g.bt, y0 = yb * g.by, x0 = xb * g.bx;
-            const int dbase = ((n * g.Tdf + t0 * g.dmt + g.dpt) * g.Hdf + y0 * g.dmh + g.dph) * g.Wdf + x0 * g.dmw + g.dpw;
+  auto do_matrix = [&]() __attribute__((always_inline)) {
+    // ================= MATRIX phase of box `cur`
+    const int nxt = cur + stride;
+    if (nxt < pg.nboxes && !(dbg & 16)) issue(nxt);                // in flight during the matrix loop
+    if (cur < pg.nboxes && !(dbg & 64)) {
+      // destination pixels of this box (byte offsets of channel c0; pixels outside the tensor: out-of-range offset)
+      {
+        int b = cur;
+        const int q1 = mdiv(b, pg.m_nbx); const int xb = b - q1 * g.nbx; b = q1;
+        const int q2 = mdiv(b, pg.m_nby); const int yb = b - q2 * g.nby; b = q2;
+        const int n = mdiv(b, pg.m_nbt); const int tb = b - n * g.nbt;
+        const int t0 = tb * g.bt, y0 = yb * g.by, x0 = xb * g.bx;
+        const int dbase = ((n * g.Tdf + t0 * g.dmt + g.dpt) * g.Hdf + y0 * g.dmh + g.dph) * g.Wdf + x0 * g.dmw + g.dpw;
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-              const int pk = rdec[a];
-              const bool v = pk >= 0 && (t0 + (pk & 0xff) < g.Td) && (y0 + ((pk >> 8) & 0xff) < g.Hd) && (x0 + ((pk >> 16) & 0xff) < g.Wd);
-              goff[a] = v ? (unsigned)((dbase + drel[a]) * g.Cpd + c0) * 4u : MD_OOB;
-              gw[a] = v ? 1.f : 0.f;
-            }
-          }
-          // matrix loop: patch fragments and resident weight fragments from LDS; no barriers
-#pragma unroll
-          for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int j = 0; j < NREP; ++j) acc[a][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          uint4 fa[2][4];
-          load_p(sK[lg], fa[0]);
-          int ko_next = sK[min(1, pg.nsteps - 1) * 4 + lg];            // tap offset of step q + 1 while step q runs
-          auto kstep = [&](const uint4* fcur, uint4* fnext, int q) {
-            // patch fragments of the next step (the last step re-reads its own: branch-free), tap offset of the one after
-            load_p(ko_next, fnext);
-            ko_next = sK[min(q + 2, pg.nsteps - 1) * 4 + lg];
-            const char* bq = bbase + q * 64;
-            uint4 fb[2][2];
-            fb[0][0] = *(const uint4*)bq; fb[0][1] = *(const uint4*)(bq + blo);
-            const uint4 ph0 = fcur[0], pl0 = fcur[1], ph1 = fcur[2], pl1 = fcur[3];
-#pragma unroll
-            for (int j = 0; j < NREP; ++j) {
-              const int cb = j & 1;
-              if (j + 1 < NREP) {
-                const char* bp = bq + (j + 1) * 16 * pg.bpitch;
-                fb[cb ^ 1][0] = *(const uint4*)bp; fb[cb ^ 1][1] = *(const uint4*)(bp + blo);
-              }
-              const uint4 wh = fb[cb][0], wl = fb[cb][1];
-              // smallest terms first: lo*hi and hi*lo, then hi*hi.  (weights, patch) operand order: D[channel][pixel]
-              acc[0][j] = mma<F16>(wh, pl0, acc[0][j]);
-              acc[1][j] = mma<F16>(wh, pl1, acc[1][j]);
-              acc[0][j] = mma<F16>(wl, ph0, acc[0][j]);
-              acc[1][j] = mma<F16>(wl, ph1, acc[1][j]);
-              acc[0][j] = mma<F16>(wh, ph0, acc[0][j]);
-              acc[1][j] = mma<F16>(wh, ph1, acc[1][j]);
-            }
-          };
-          int q = (dbg & 2) ? pg.nsteps : 0;
-          for (; q + 1 < pg.nsteps; q += 2) { kstep(fa[0], fa[1], q); kstep(fa[1], fa[0], q + 1); }
-          if (q < pg.nsteps) kstep(fa[0], fa[1], q);
+        for (int a = 0; a < 2; ++a) {
+          const int pk = rdec[a];
+          const bool v = pk >= 0 && (t0 + (pk & 0xff) < g.Td) && (y0 + ((pk >> 8) & 0xff) < g.Hd) && (x0 + ((pk >> 16) & 0xff) < g.Wd);
+          goff[a] = v ? (unsigned)((dbase + drel[a]) * g.Cpd + c0) * 4u : MD_OOB;
+          gw[a] = v ? 1.f : 0.f;
         }
-      } else {
-        // ================= MOVE phase: next box's patch into LDS, then this box out to HBM
-        const int nxt = cur + stride;
-        // raw output of the differentiated unit at this box's pixels (fused BatchNorm-backward reduction): the first JE
-        // tiles are requested before the commit, the rest right after it (when the patch registers are free again)
-        constexpr int JE = NREP <= 3 ? NREP : (NREP + 1) / 2;
-        f32x4 yv[FUSE ? NREP : 1][2];
-        auto request_y = [&](int jb, int je) {
+      }
+      // matrix loop: patch fragments and resident weight fragments from LDS; no barriers
 #pragma unroll
-          for (int j = 0; j < NREP; ++j) {
-            if (j >= jb && j < je) {
-              const bool colok = c0 + j * 16 < g.Cpd && cur < pg.nboxes;
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-              for (int a = 0; a < 2; ++a) yv[j][a] = buf_load4_pinned(yrs, colok ? goff[a] + j * 64u : MD_OOB);
-            }
-          }
-        };
-        if constexpr (FUSE) request_y(0, JE);
-        if (nxt < pg.nboxes && !(dbg & 8)) commit();
-        if constexpr (FUSE) request_y(JE, NREP);
-        if (cur < pg.nboxes && !(dbg & 32)) {
+        for (int j = 0; j < NREP; ++j) acc[a][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      uint4 fa[2][4];
+      load_p(sK[lg], fa[0]);
+      int ko_next = sK[min(1, pg.nsteps - 1) * 4 + lg];            // tap offset of step q + 1 while step q runs
+      // weight fragments stream through registers two channel tiles ahead of their use, across step boundaries as well:
+      // one tile's six MFMAs (96 cycles) do not cover an LDS read under load, two tiles' do
+      auto load_w = [&](const char* bq, int j, uint4* f) __attribute__((always_inline)) {
+        const char* bp = bq + j * 16 * pg.bpitch;
+        f[0] = *(const uint4*)bp; f[1] = *(const uint4*)(bp + blo);
+      };
+      uint4 w0[2], w1[2];
+      load_w(bbase, 0, w0); load_w(bbase, 1 % NREP, w1);
+      auto kstep = [&](const uint4* fcur, uint4* fnext, int q) __attribute__((always_inline)) {
+        // patch fragments of the next step (the last step re-reads its own: branch-free), tap offset of the one after
+        load_p(ko_next, fnext);
+        ko_next = sK[min(q + 2, pg.nsteps - 1) * 4 + lg];
+        __builtin_amdgcn_sched_barrier(0);
+        const char* bq = bbase + q * 64;
+        const char* bqn = bbase + min(q + 1, pg.nsteps - 1) * 64;
+        const uint4 ph0 = fcur[0], pl0 = fcur[1], ph1 = fcur[2], pl1 = fcur[3];
+        uint4 wc[2] = {w0[0], w0[1]}, wn[2] = {w1[0], w1[1]};
 #pragma unroll
-          for (int j = 0; j < NREP; ++j) {
-            const bool colok = c0 + j * 16 < g.Cpd;
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-              const unsigned off = (colok && !(dbg & 4)) ? goff[a] + j * 64u : MD_OOB;
-              f32x4 v = acc[a][j];
-              if (accumulate) v += buf_load4v(drs, off);
-              if constexpr (FUSE) {
-                const f32x4 sc = *(const f32x4*)(sBn + c0 + j * 16), sh = *(const f32x4*)(sBn + bns + c0 + j * 16);
-                const f32x4 mu = *(const f32x4*)(sBn + 2 * bns + c0 + j * 16), is = *(const f32x4*)(sBn + 3 * bns + c0 + j * 16);
-                const f32x4 y = yv[j][a];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                  const float pre = fmaf(y[r], sc[r], sh[r]);
-                  v[r] *= md_dleaky(pre, bw.slope);                    // g = dA * leaky'(bn(y))
-                  const float gm = v[r] * gw[a];
-                  s1[j][r] += gm; s2[j][r] = fmaf(gm, (y[r] - mu[r]) * is[r], s2[j][r]);
-                }
-              } else if (stats) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { const float vm = v[r] * gw[a]; s1[j][r] += vm; s2[j][r] = fmaf(vm, v[r], s2[j][r]); }
-              }
-              buf_store4(drs, off, v);
-            }
-          }
+        for (int j = 0; j < NREP; ++j) {
+          uint4 wp2[2];
+          if (j + 2 < NREP) load_w(bq, j + 2, wp2); else load_w(bqn, (j + 2 - NREP) % NREP, wp2);
+          __builtin_amdgcn_sched_barrier(0);            // keep the reads HERE: the scheduler would sink them to their use
+          const uint4 wh = wc[0], wl = wc[1];
+          // smallest terms first: lo*hi and hi*lo, then hi*hi.  (weights, patch) operand order: D[channel][pixel]
+          acc[0][j] = mma<F16>(wh, pl0, acc[0][j]);
+          acc[1][j] = mma<F16>(wh, pl1, acc[1][j]);
+          acc[0][j] = mma<F16>(wl, ph0, acc[0][j]);
+          acc[1][j] = mma<F16>(wl, ph1, acc[1][j]);
+          acc[0][j] = mma<F16>(wh, ph0, acc[0][j]);
+          acc[1][j] = mma<F16>(wh, ph1, acc[1][j]);
+          __builtin_amdgcn_sched_barrier(0);
+          wc[0] = wn[0]; wc[1] = wn[1]; wn[0] = wp2[0]; wn[1] = wp2[1];
         }
-        cur = nxt;
+        w0[0] = wc[0]; w0[1] = wc[1]; w1[0] = wn[0]; w1[1] = wn[1];
+      };
+      int q = (dbg & 2) ? pg.nsteps : 0;
+      for (; q + 1 < pg.nsteps; q += 2) { kstep(fa[0], fa[1], q); kstep(fa[1], fa[0], q + 1); }
+      if (q < pg.nsteps) kstep(fa[0], fa[1], q);
+    }
+  };
+  auto do_move = [&]() __attribute__((always_inline)) {
+    // ================= MOVE phase: next box's patch into LDS, then this box out to HBM
+    const int nxt = cur + stride;
+    // raw output of the differentiated unit at this box's pixels (fused BatchNorm-backward reduction): tiles are requested
+    // YD ahead of their use -- the first YD before the commit, the rest as the epilogue walks the tiles -- so that at most
+    // YD + 1 tiles of y are live next to the accumulators
+    constexpr int YD = NREP <= 3 ? NREP : 2;
+    f32x4 yv[FUSE ? NREP : 1][2];
+    auto request_y = [&](int j) __attribute__((always_inline)) {
+      const bool colok = c0 + j * 16 < g.Cpd && cur < pg.nboxes;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) yv[FUSE ? j : 0][a] = buf_load4_pinned(yrs, colok ? goff[a] + j * 64u : MD_OOB);
+    };
+    if constexpr (FUSE) {
+#pragma unroll
+      for (int j = 0; j < YD; ++j) request_y(j);
+    }
+    if (nxt < pg.nboxes && !(dbg & 8)) commit();
+    if (cur < pg.nboxes && !(dbg & 32)) {
+#pragma unroll
+      for (int j = 0; j < NREP; ++j) {
+        if constexpr (FUSE) { if (j + YD < NREP) { request_y(j + YD); __builtin_amdgcn_sched_barrier(0); } }
+        const bool colok = c0 + j * 16 < g.Cpd;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const unsigned off = (colok && !(dbg & 4)) ? goff[a] + j * 64u : MD_OOB;
+          f32x4 v = acc[a][j];
+          if (accumulate) v += buf_load4v(drs, off);
+          if constexpr (FUSE) {
+            const f32x4 sc = *(const f32x4*)(sBn + c0 + j * 16), sh = *(const f32x4*)(sBn + bns + c0 + j * 16);
+            const f32x4 mu = *(const f32x4*)(sBn + 2 * bns + c0 + j * 16), is = *(const f32x4*)(sBn + 3 * bns + c0 + j * 16);
+            const f32x4 y = yv[j][a];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float pre = fmaf(y[r], sc[r], sh[r]);
+              v[r] *= md_dleaky(pre, bw.slope);                    // g = dA * leaky'(bn(y))
+              const float gm = v[r] * gw[a];
+              s1[j][r] += gm; s2[j][r] = fmaf(gm, (y[r] - mu[r]) * is[r], s2[j][r]);
+            }
+          } else if (stats) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float vm = v[r] * gw[a]; s1[j][r] += vm; s2[j][r] = fmaf(vm, v[r], s2[j][r]); }
+          }
+          buf_store4(drs, off, v);
+        }
       }
     }
-    __syncthreads();                         // closes the phase: patches written / read by either team are settled
+  };
+
+#ifdef MD_PERS_LOCKSTEP
+  {
+    // lock-step schedule: team 1 runs one phase behind team 0; a workgroup barrier closes every phase
+    for (int s = 0; s < 2 * niter + 1; ++s) {
+      const int ph = s - team;
+      if (ph >= 0 && ph < 2 * niter) {
+        if ((ph & 1) == 0) do_matrix();
+        else { do_move(); cur += stride; }
+      }
+      __syncthreads();                       // closes the phase: patches written / read by either team are settled
+    }
   }
+#else
+  {
+    // decoupled schedule: the weights are read-only and each team owns its patch buffer, so the only hand-offs are inside
+    // a team (patch written by all four waves -> read by all four; read by all -> overwritten).  A four-wave barrier on an
+    // LDS counter replaces the workgroup barrier; the teams drift freely, so neither waits for the other's longer phase.
+    int* ctr = (int*)(sm + pg.off_sync) + team * 16;
+    int target = 0;
+    auto team_sync = [&]() {
+      target += 4;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    while (cur < pg.nboxes) {
+      do_matrix();
+      team_sync();                           // every wave of the team has read the patch of `cur`
+      do_move();
+      team_sync();                           // the patch of the next box is complete
+      cur += stride;
+    }
+    __syncthreads();                         // both teams are done with their patches (the reduction scratch aliases them)
+  }
+#endif
 
   // ---- one partial row per workgroup: sum over the 16 pixel lanes, then over the eight waves (fixed order)
   if (stats) {
@@ -400,6 +441,8 @@ bool pers_finish(PersGeom* pg, size_t* lds_bytes, int* grid) {
   pg->sc_stride = g.C8 * 8; pg->bn_stride = g.N16;
   pg->off_sc = (int)off; off += (size_t)2 * pg->sc_stride * 4;
   pg->off_bn = (int)off; off += (size_t)4 * pg->bn_stride * 4;
+  off = (off + 15) & ~(size_t)15;
+  pg->off_sync = (int)off; off += 128;             // two team counters, 64 B apart
   if (off > (size_t)(160 * 1024)) return false;
   *lds_bytes = off;
   *grid = pers_num_cus();
@@ -410,7 +453,7 @@ size_t pers_bres_bytes(int Kc8, int N16) {
   int u = md_cdiv(Kc8, 4) * 4; while ((u & 3) != 2) ++u;
   return (size_t)2 * N16 * u * 16;
 }
-size_t pers_fixed_bytes(int Cps, int N16) { return (size_t)PM * 8 + (size_t)(2 * (Cps + 8) + 4 * N16) * 4 + 256; }
+size_t pers_fixed_bytes(int Cps, int N16) { return (size_t)PM * 8 + (size_t)(2 * (Cps + 8) + 4 * N16) * 4 + 256 + 144; }
 
 int pers_launch(const PersGeom& pg, size_t lds, int grid, bool f16, const float* src, const float* ps, const float* psh, float slope,
                 const float* wp, float* dst, float* stat, int accumulate, const PersBwd& bw, hipStream_t s) {

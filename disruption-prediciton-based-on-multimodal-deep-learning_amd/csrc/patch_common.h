@@ -109,7 +109,7 @@ struct PersGeom {
   int nsteps;               // k32 steps = ceil(Kc8 / 4)
   int bpitch;               // resident weight row pitch in bytes, (bpitch / 16) % 4 == 2
   int off_bres;             // LDS byte offsets
-  int off_k, off_row, off_sc, off_red, off_bn;
+  int off_k, off_row, off_sc, off_red, off_bn, off_sync;
   int nit;                  // patch items per thread
   int patch_bytes;          // LDS bytes of one team's patch ([pixel][hi | lo | pad])
   int sc_stride, bn_stride; // floats between the scale | shift (| mean | invstd) rows in LDS

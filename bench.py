@@ -90,7 +90,8 @@ def pmc_traffic(dom):
     if not files:
         return None, "no PMC pass committed"
     fams = json.load(open(files[-1]))["families"]
-    sel = [v for k, v in fams.items() if k.startswith(dom)]
+    doms = ("k_conv_patch", "k_conv_pers") if dom == "k_conv_patch" else (dom,)     # the persistent form is the same family
+    sel = [v for k, v in fams.items() if k.startswith(doms)]
     n = sum(v["launches_per_step"] for v in sel)
     if not n:
         return None, "kernel family not in " + os.path.basename(files[-1])
@@ -228,7 +229,7 @@ def main():
     if rank == 0:
         clips = B_PER_GPU * world * args.steps
         value = clips / dt
-        names = ["k_conv_patch<fp16 split>(forward)", "k_conv_patch<bf16 split>(data-gradient)", "k_wgrad_patch(+reduce)"]
+        names = ["k_conv_patch|k_conv_pers<fp16 split>(forward)", "k_conv_patch|k_conv_pers<bf16 split>(data-gradient)", "k_wgrad_patch(+reduce)"]
         kern = []
         for (ms, n, fl), nm in zip(prof, names):
             if n:

@@ -6,9 +6,9 @@ def fam(n):
     m = re.search(r'(k_[a-z0-9_]+)', n)
     if m:
         f = m.group(1)
-        if f == 'k_conv_patch':
-            a = re.search(r'k_conv_patch<(\w+), (\w+)', n)
-            return 'k_conv_patch(forward)' if a.group(1) == 'true' else 'k_conv_patch(data-gradient)'
+        if f in ('k_conv_patch', 'k_conv_pers'):
+            a = re.search(r'k_conv_p\w+<(\w+), (\w+)', n)
+            return f + ('(forward)' if a.group(1) == 'true' else '(data-gradient)')
         return f
     return 'at::native / other'
 tot = {c: collections.defaultdict(float) for c in ('FETCH_SIZE', 'WRITE_SIZE')}

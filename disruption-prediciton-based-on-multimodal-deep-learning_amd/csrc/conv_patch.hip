@@ -55,16 +55,12 @@ __device__ __forceinline__ void stage_image(__amdgpu_buffer_rsrc_t src, int Cpit
       const int pixel = pix[u] & 0x0fffffff;
       float v[8] = {va[u].x, va[u].y, va[u].z, va[u].w, vb[u].x, vb[u].y, vb[u].z, vb[u].w};
       if (prologue) {
-        const float keep = (pix[u] & 0x20000000) ? 0.f : 1.f;       // padding stays zero after the activation
         // (scale/shift of the channel padding are zero in LDS: a padded channel is 0 in memory and stays leaky(0*0+0) = 0,
         // so no per-element "does this channel exist" test -- it compiled into eight dependent LDS round trips per item)
         const float* sc = sScale + c0 + c8s[u] * 8; const float* sh = sShift + c0 + c8s[u] * 8;
         const f32x4 sc0 = *(const f32x4*)sc, sc1 = *(const f32x4*)(sc + 4), sh0 = *(const f32x4*)sh, sh1 = *(const f32x4*)(sh + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = md_leaky(fmaf(v[e], sc0[e], sh0[e]), pslope) * keep;
-          v[4 + e] = md_leaky(fmaf(v[4 + e], sc1[e], sh1[e]), pslope) * keep;
-        }
+        bn_leaky8(v, sc0, sc1, sh0, sh1, pslope);
+        if (pix[u] & 0x20000000) zero8(v);                          // padding stays zero after the activation
       }
       uint4 hi, lo;
       if (presplit) { hi = __builtin_bit_cast(uint4, va[u]); lo = __builtin_bit_cast(uint4, vb[u]); }
@@ -870,8 +866,7 @@ __device__ __forceinline__ void stage_image_ptr(const float* __restrict__ src, i
       float v[8] = {va[u].x, va[u].y, va[u].z, va[u].w, vb[u].x, vb[u].y, vb[u].z, vb[u].w};
       if (prologue && inside) {
         const float* sc = sScale + c0 + c8s[u] * 8; const float* sh = sShift + c0 + c8s[u] * 8;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = md_leaky(fmaf(v[e], sc[e], sh[e]), pslope);
+        bn_leaky8(v, *(const f32x4*)sc, *(const f32x4*)(sc + 4), *(const f32x4*)sh, *(const f32x4*)(sh + 4), pslope);
         if (half) { v[4] = v[5] = v[6] = v[7] = 0.f; }
       }
       uint4 hi, lo;
@@ -1201,8 +1196,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void k_wgrad_patch_pf(
         if (prologue && ((xfl >> (2 * u)) & 1)) {
           const int c8 = (xloc[u] >> 24) & 255;
           const float* sc = sScale + c8 * 8; const float* sh = sShift + c8 * 8;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = md_leaky(fmaf(v[e], sc[e], sh[e]), pslope);
+          bn_leaky8(v, *(const f32x4*)sc, *(const f32x4*)(sc + 4), *(const f32x4*)sh, *(const f32x4*)(sh + 4), pslope);
           if ((xfl >> (2 * u)) & 2) { v[4] = v[5] = v[6] = v[7] = 0.f; }
         }
         uint4 hi, lo;

@@ -186,15 +186,11 @@ __global__ __launch_bounds__(512) void k_conv_pers(
       if (u < pg.nit && it_lds[u] >= 0) {
         float v[8] = {va[u][0], va[u][1], va[u][2], va[u][3], vb[u][0], vb[u][1], vb[u][2], vb[u][3]};
         if (prologue) {
-          const float keep = ((inmask >> u) & 1u) ? 1.f : 0.f;        // zero padding stays zero after the activation
           const int c8 = (int)((it_pd[u] >> 24) & 63u);
           const f32x4 sc0 = *(const f32x4*)(sScale + c8 * 8), sc1 = *(const f32x4*)(sScale + c8 * 8 + 4);
           const f32x4 sh0 = *(const f32x4*)(sShift + c8 * 8), sh1 = *(const f32x4*)(sShift + c8 * 8 + 4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] = md_leaky(fmaf(v[e], sc0[e], sh0[e]), pslope) * keep;
-            v[4 + e] = md_leaky(fmaf(v[4 + e], sc1[e], sh1[e]), pslope) * keep;
-          }
+          bn_leaky8(v, sc0, sc1, sh0, sh1, pslope);
+          if (!((inmask >> u) & 1u)) zero8(v);                         // zero padding stays zero after the activation
         }
         uint4 hi, lo;
         if (presplit) { hi = __builtin_bit_cast(uint4, va[u]); lo = __builtin_bit_cast(uint4, vb[u]); }

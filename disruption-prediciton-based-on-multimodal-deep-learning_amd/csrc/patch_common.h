@@ -78,6 +78,38 @@ __device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
   lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
+
+// BatchNorm-on-read + LeakyReLU of one 8-channel chunk in packed fp32 math (v_pk_fma_f32, v_pk_mul_f32): per element
+// the same operations as  md_leaky(fmaf(v, scale, shift), slope) , so the result is bit-identical.  md_leaky decides
+// between max(x, slope x) (0 <= slope <= 1) and the select form per ELEMENT (8 compares + 17 selects per chunk in the
+// generated code); here the decision is taken once per call on the wave-uniform slope.
+__device__ __forceinline__ void bn_leaky8(float* v, f32x4 sc0, f32x4 sc1, f32x4 sh0, f32x4 sh1, float slope) {
+  const f32x2 s[4] = {{sc0[0], sc0[1]}, {sc0[2], sc0[3]}, {sc1[0], sc1[1]}, {sc1[2], sc1[3]}};
+  const f32x2 h[4] = {{sh0[0], sh0[1]}, {sh0[2], sh0[3]}, {sh1[0], sh1[1]}, {sh1[2], sh1[3]}};
+  const f32x2 sl = {slope, slope};
+  if (slope >= 0.f && slope <= 1.f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x2 x = {v[2 * i], v[2 * i + 1]};
+      const f32x2 pre = __builtin_elementwise_fma(x, s[i], h[i]);
+      const f32x2 r = __builtin_elementwise_max(pre, pre * sl);
+      v[2 * i] = r[0]; v[2 * i + 1] = r[1];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x2 x = {v[2 * i], v[2 * i + 1]};
+      const f32x2 pre = __builtin_elementwise_fma(x, s[i], h[i]);
+      const f32x2 t = pre * sl;
+      v[2 * i] = pre[0] > 0.f ? pre[0] : t[0]; v[2 * i + 1] = pre[1] > 0.f ? pre[1] : t[1];
+    }
+  }
+}
+__device__ __forceinline__ void zero8(float* v) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = 0.f;
+}
+
 // x / d for 0 <= x, x * d < 2^32, with magic = floor(2^32 / d) + 1 (0 encodes d == 1)
 __device__ __forceinline__ int mdiv(int x, unsigned magic) { return magic ? (int)__umulhi((unsigned)x, magic) : x; }
 

@@ -1,5 +1,6 @@
 """Inference path of the reference's ``src/utils/utility.py``: sliding-window disruption-probability curves for one shot
-(``generate_prob_curve`` :896-977, ``generate_prob_curve_from_0D`` :979-1066), ``moving_avarage_smoothing`` (:872-893) and
+(``generate_prob_curve`` :896-977, ``generate_prob_curve_from_0D`` :979-1066, ``generate_prob_curve_from_multi`` :1068-1178),
+``moving_avarage_smoothing`` (:872-893) and
 ``measure_computation_time`` (:1201-1230), MI355X-first.  SURVEY 8(f) item 4.
 
 The reference builds every window on the host (cv2.imread of seq_len files per window, fp32, crop, normalise, transpose),
@@ -194,6 +195,108 @@ def generate_prob_curve_from_0D(model: torch.nn.Module, device: str = "cuda:0", 
     model.to(device)
     p0, _ = series_window_probabilities(model, torch.from_numpy(values).to(device), seq_len, dist, windows_per_launch)
     time_x, prob_list = assemble_0D_curve(p0.tolist(), seq_len, t_start)
+    print("\n(Info) flat-top : {:.3f}(s) | thermal quench : {:.3f}(s) | current quench : {:.3f}(s)\n".format(
+        row["tftsrt"], row["tTQend"], row["tipminf"]))
+    return time_x, prob_list
+
+
+def multi_window_tables(n_frames: int, ts_time: np.ndarray, frame_srt: int, frame_end: int, t_srt: float, t_end: float,
+                        vis_seq_len: int, ts_seq_len: int, dt: float, tau: int):
+    """Frame indices and last 0D row of every window, as MultiModalDataset.__init__ matches them from the END of the shot
+    backwards (utility.py:579-611; literal, including :605's use of the first-stage list length)."""
+    video_indices = list(reversed(range(frame_end, frame_srt, -tau)))
+    ts_idx_end = len(ts_time) - int(np.sum(np.asarray(ts_time) > t_end))
+    ts_idx_start = int(t_srt / dt)
+    ts_indices = list(reversed(range(ts_idx_end, ts_idx_start, -tau)))
+    if len(video_indices) > len(ts_indices):
+        video_indices = video_indices[-len(ts_indices):]
+    elif len(video_indices) < len(ts_indices):
+        ts_indices = ts_indices[-len(video_indices):]
+    frames_of = [list(range(n_frames))[idx + 1: idx - tau * vis_seq_len + 1: -tau][::-1] for idx in video_indices if idx > vis_seq_len * tau]
+    ts_sel = [idx for idx in ts_indices if idx > ts_seq_len * tau]
+    if len(frames_of) > len(ts_sel):
+        frames_of = frames_of[-len(ts_indices):]
+    elif len(frames_of) < len(ts_sel):
+        ts_sel = ts_sel[-len(frames_of):]
+    return frames_of, ts_sel
+
+
+def multi_window_probabilities(model: torch.nn.Module, frames: torch.Tensor, values: torch.Tensor, frames_of, ts_sel,
+                               ts_seq_len: int, tau: int, crop_size: int = 128, windows_per_launch: int = 1):
+    """frames (F, Hr, Wr, 3) uint8 and scaled 0D rows (n_rows, n_cols) fp32, both on the GPU; one fused-model forward per
+    ``windows_per_launch`` windows; softmax column 0 / arg-max collected on the device."""
+    ops.require_cuda(frames)
+    values = values.contiguous().float()
+    n = len(ts_sel)
+    dev = frames.device
+    p0 = torch.zeros(n, device=dev, dtype=torch.float32)
+    cls = torch.zeros(n, device=dev, dtype=torch.int64)
+    if n == 0:
+        return p0.cpu().numpy(), cls.cpu().numpy()
+    if any(len(f) != len(frames_of[0]) for f in frames_of):
+        raise RuntimeError("generate_prob_curve_from_multi: windows of unequal length (shot shorter than one clip)")
+    fidx = torch.tensor(frames_of, dtype=torch.int64, device=dev)                          # (n, vis_seq_len)
+    steps = torch.arange(ts_seq_len, device=dev) * tau
+    ridx = (torch.tensor(ts_sel, dtype=torch.int64, device=dev) - ts_seq_len * tau + 1).view(-1, 1) + steps.view(1, -1)   # rows idx_srt+1 ..
+    model.eval()
+    W = max(1, int(windows_per_launch))
+    with torch.no_grad():
+        for at in range(0, n, W):
+            m = min(W, n - at)
+            clip = preprocess_clips(frames[fidx[at:at + m]], crop_size)                   # gather of uint8 frames, then one launch
+            out = model(clip, values[ridx[at:at + m]].contiguous())
+            _softmax_columns(out, p0, cls, at)
+    return p0.cpu().numpy(), cls.cpu().numpy()
+
+
+def _interp_extrapolate(x, xp, fp):
+    """scipy.interpolate.interp1d(kind="linear", fill_value="extrapolate") for increasing xp."""
+    x, xp, fp = np.asarray(x, np.float64), np.asarray(xp, np.float64), np.asarray(fp, np.float64)
+    i = np.clip(np.searchsorted(xp, x, side="right") - 1, 0, len(xp) - 2)
+    return fp[i] + (fp[i + 1] - fp[i]) / (xp[i + 1] - xp[i]) * (x - xp[i])
+
+
+def assemble_multi_curve(prob_list, t_srt: float, t_end: float, tau: int):
+    """utility.py:1133-1170: (time_x, interpolated + smoothed curve).  The reference function returns the RAW list beside time_x."""
+    dt_end, interval = 1.0, tau
+    n0, n1 = int(t_srt * FPS / interval), int(dt_end * FPS / interval)
+    body = list(prob_list)[1:]
+    total = _startup_correction([0] * n0 + body + [0] * n1, FPS * 1.0 / interval)
+    x_srt = [i * interval / FPS for i in range(0, n0)]
+    x_prob = [x_srt[-1] + (i + 1) * 1 / FPS * interval for i in range(0, len(body) + n1)]
+    q = _interp_extrapolate(np.linspace(0, t_end + dt_end, num=len(total) * interval, endpoint=True), x_srt + x_prob, total)
+    q = moving_avarage_smoothing(q, 16, "center")
+    return np.linspace(0, t_end + dt_end, num=len(q), endpoint=True), q
+
+
+def generate_prob_curve_from_multi(file_path: Optional[str], model: torch.nn.Module, device: str = "cuda:0",
+                                   save_dir: Optional[str] = None,
+                                   ts_data_dir: Optional[str] = "./dataset/KSTAR_Disruption_ts_data_extend.csv",
+                                   ts_cols: Optional[List] = None,
+                                   shot_list_dir: Optional[str] = "./dataset/KSTAR_Disruption_Shot_List_extend.csv",
+                                   shot_num: Optional[int] = None, vis_seq_len: Optional[int] = None,
+                                   ts_seq_len: Optional[int] = None, dist: Optional[int] = None, dt: Optional[float] = None,
+                                   scaler=None, tau: int = 1, frames: Optional[torch.Tensor] = None, windows_per_launch: int = 1):
+    """Reference utility.py:1068-1178; returns (time_x, prob_list) like the reference: the time axis of the interpolated
+    curve and the raw per-window probabilities.  The scaler is fitted on the shot's own rows when none is given (:573-578)."""
+    row = _shot_row(shot_list_dir, shot_num)
+    ts = _shot_series(ts_data_dir, ts_cols, shot_num)
+    if scaler is None:
+        from sklearn.preprocessing import RobustScaler
+        values = RobustScaler().fit_transform(ts[ts_cols].values)
+    else:
+        values = scaler.transform(ts[ts_cols].values)
+    values = np.ascontiguousarray(values, dtype=np.float32)
+    model.to(device)
+    if frames is None:
+        frames = load_frame_stack(file_path, device)
+    frames = frames.to(device)
+    frames_of, ts_sel = multi_window_tables(frames.shape[0], ts.time.values, int(row["frame_startup"]), int(row["frame_cutoff"]),
+                                            row["tftsrt"], row["tipminf"], vis_seq_len, ts_seq_len, dt, tau)
+    p0, _ = multi_window_probabilities(model, frames, torch.from_numpy(values).to(device), frames_of, ts_sel, ts_seq_len, tau, 128,
+                                       windows_per_launch)
+    prob_list = p0.tolist()
+    time_x, _ = assemble_multi_curve(prob_list, ts.time.values[ts_sel[0]], ts.time.values[ts_sel[-1]], tau)
     print("\n(Info) flat-top : {:.3f}(s) | thermal quench : {:.3f}(s) | current quench : {:.3f}(s)\n".format(
         row["tftsrt"], row["tTQend"], row["tipminf"]))
     return time_x, prob_list

@@ -6,6 +6,8 @@
   * ``series_windows``          DatasetFor0D (src/utils/utility.py:475-513)
   * ``assemble_video_curve``    generate_prob_curve's post-processing           (src/utils/utility.py:950-961)
   * ``assemble_0D_curve``       generate_prob_curve_from_0D's post-processing   (src/utils/utility.py:1040-1057)
+  * ``multi_window_tables``     MultiModalDataset.__init__ index matching       (src/utils/utility.py:579-611), literal
+  * ``assemble_multi_curve``    generate_prob_curve_from_multi's post-processing (src/utils/utility.py:1133-1170)
   * ``moving_average``          moving_avarage_smoothing                        (src/utils/utility.py:872-893)
   * ``threshold_predictions``   evaluate's decision rule                        (src/evaluate.py:56-58, 75-76)
 
@@ -101,3 +103,52 @@ def assemble_0D_curve(probs, seq_len: int, t_start: float):
 def threshold_predictions(p_disrupt: np.ndarray, threshold: float) -> np.ndarray:
     """evaluate.py:57-58: label 1 (normal) unless softmax[:,0] > threshold."""
     return np.logical_not(p_disrupt > np.float32(threshold)).astype(np.int64)
+
+
+def multi_window_tables(n_frames: int, ts_time: np.ndarray, frame_srt: int, frame_end: int, t_srt: float, t_end: float,
+                        vis_seq_len: int, ts_seq_len: int, dt: float, tau: int):
+    """(frame index list per window, last 0D row per window) exactly as MultiModalDataset builds them (:579-611), including
+    the second length match, which truncates by the length of the FIRST-stage list (``ts_indices``, :606), not by the filtered one."""
+    video_indices = [i for i in reversed(range(frame_end, frame_srt, -tau))]                            # :580
+    ts_idx_end = len(ts_time) - int(np.sum(ts_time > t_end))                                            # :583
+    ts_idx_start = int(t_srt / dt)                                                                      # :584
+    ts_indices = [i for i in reversed(range(ts_idx_end, ts_idx_start, -tau))]                           # :586
+    if len(video_indices) > len(ts_indices):
+        video_indices = video_indices[-len(ts_indices):]
+    elif len(video_indices) < len(ts_indices):
+        ts_indices = ts_indices[-len(video_indices):]
+    paths = list(range(n_frames))
+    video_frames = [paths[idx + 1: idx - tau * vis_seq_len + 1: -tau][::-1] for idx in video_indices if idx > vis_seq_len * tau]   # :596-598
+    ts_sel = [idx for idx in ts_indices if idx > ts_seq_len * tau]                                       # :600-602
+    if len(video_frames) > len(ts_sel):
+        video_frames = video_frames[-len(ts_indices):]                                                   # :605 (sic)
+    elif len(video_frames) < len(ts_sel):
+        ts_sel = ts_sel[-len(video_frames):]
+    return video_frames, ts_sel
+
+
+def multi_ts_window(values: np.ndarray, idx_end: int, ts_seq_len: int, tau: int) -> np.ndarray:       # :680-684
+    idx_srt = idx_end - ts_seq_len * tau
+    return values[idx_srt + 1: idx_end + 1][::tau, :]
+
+
+def _interp_extrap(x, xp, fp):
+    """scipy interp1d(kind='linear', fill_value='extrapolate') on increasing xp."""
+    x, xp, fp = np.asarray(x, np.float64), np.asarray(xp, np.float64), np.asarray(fp, np.float64)
+    i = np.clip(np.searchsorted(xp, x, side="right") - 1, 0, len(xp) - 2)
+    slope = (fp[i + 1] - fp[i]) / (xp[i + 1] - xp[i])
+    return fp[i] + slope * (x - xp[i])
+
+
+def assemble_multi_curve(probs, t_srt: float, t_end: float, tau: int):
+    """t_srt / t_end: times of the first / last selected 0D row (:1133-1134).  Returns (time_x, smoothed curve); the reference
+    function itself returns (time_x, the RAW per-window probabilities)."""
+    dt_end, interval = 1.0, tau
+    n0, n1 = int(t_srt * FPS / interval), int(dt_end * FPS / interval)
+    total = [0] * n0 + list(probs)[1:] + [0] * n1                                                        # :1140
+    total = _startup_correction(total, FPS * 1.0 / interval)
+    x_srt = [i * interval / FPS for i in range(0, n0)]
+    x_prob = [x_srt[-1] + (i + 1) * 1 / FPS * interval for i in range(0, len(list(probs)[1:]) + n1)]
+    q = _interp_extrap(np.linspace(0, t_end + dt_end, num=len(total) * interval, endpoint=True), np.array(x_srt + x_prob), np.array(total, dtype=np.float64))
+    q = moving_average(q, 16, "center")                                                                  # :1160
+    return np.linspace(0, t_end + dt_end, num=len(q), endpoint=True), q

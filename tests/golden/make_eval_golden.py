@@ -33,7 +33,8 @@ class _Quiet:
 
 
 FRAMES = {}
-for name, attrs in (("cv2", dict(imread=lambda p: FRAMES[p])), ("glob2", dict(glob=lambda pat: list(FRAMES))),
+for name, attrs in (("cv2", dict(imread=lambda p: FRAMES[p])),
+                    ("glob2", dict(glob=lambda pat: [k for k in FRAMES if os.path.dirname(k) == os.path.dirname(pat)])),
                     ("torchvision", {}), ("torchvision.transforms", {})):
     m = types.ModuleType(name)
     for k, v in attrs.items():
@@ -166,6 +167,49 @@ def main():
     hook.remove()
     rec["ts/time_x"], rec["ts/prob"], rec["ts/window_softmax"] = np.asarray(time_x), np.asarray(prob, dtype=np.float64), np.stack(seen)
     print("0D curve", len(prob), "windows", len(seen))
+    # ---- DatasetForVideo (src/dataset.py:31-144): clip index / label logic and the deterministic preprocessing -----------------
+    import pandas as pd
+    from src.dataset import DatasetForVideo          # reference
+    for i in range(NFRAMES):
+        FRAMES["/shots/%d/%06d.jpg" % (SHOT, i)] = frames[i]
+    df = pd.DataFrame({"shot": [SHOT], "frame_tipminf": [250], "frame_startup": [FRAME_SRT]})
+    dv = DatasetForVideo(["/shots/%d" % SHOT], df, augmentation=False, crop_size=128, seq_len=CLIP, dist=DIST)
+    rec["dsv/n"] = np.array(len(dv)); rec["dsv/labels"] = np.asarray(dv.labels)
+    rec["dsv/cfg"] = np.array([250, FRAME_SRT, CLIP, DIST, 128])
+    for i in (0, len(dv) - 1):
+        clip, lab = dv[i]
+        rec["dsv/clip%d" % i] = MG.subsample(clip, 96)
+    print("DatasetForVideo", len(dv), dv.labels)
+    # ---- generate_prob_curve_from_multi (utility.py:1068-1178): MultiModalDataset index matching + curve assembly --------------
+    from src.models.MultiModal import MultiModalModel     # reference
+    SHOT2, SRT2, END2 = 21311, 20, 200
+    with open(shot_csv, "a", encoding="euc-kr") as f:
+        f.write("%d,1.05,0.3,1.1,%d,%d\n" % (SHOT2, SRT2, END2))
+    t2 = np.arange(120) * (4.0 / 210)
+    with open(ts_csv, "a") as f:
+        for i in range(len(t2)):
+            f.write("%.9f,%d," % (t2[i], SHOT2) + ",".join("%.9g" % v for v in vals[i]) + "\n")
+    torch.manual_seed(77)
+    AVm = dict(image_size=128, patch_size=16, n_frames=CLIP, dim=16, depth=1, n_heads=2, in_channels=3, d_head=8, dropout=0.0,
+               embedd_dropout=0.0, scale_dim=2, pool="mean")
+    A0m = dict(n_features=len(TS_COLS), kernel_size=3, feature_dims=16, max_len=CLIP, n_layers=1, n_heads=2, dim_feedforward=24,
+               dropout=0.0)
+    mm = MultiModalModel(2, dict(AVm), dict(A0m))
+    for mod in mm.modules():
+        if type(mod).__name__ == "NoiseLayer":
+            mod.std = 0.0
+    with torch.no_grad():                                  # pixel-scale inputs: keep the patch embedding O(1)
+        mm.encoder_video.to_patch_embedding[1].weight.mul_(0.02)
+    for k, v in mm.state_dict().items():
+        rec["multi/sd/" + k] = v.numpy().copy()
+    seen = []
+    hook = mm.register_forward_hook(lambda m, i, o: seen.append(torch.softmax(o, 1)[0].detach().numpy().copy()))
+    time_x, prob = ref_util.generate_prob_curve_from_multi("/frames", mm, "cpu", None, ts_csv, TS_COLS, shot_csv, SHOT2, CLIP, CLIP,
+                                                           DIST, 4.0 / 210, None, 1)
+    hook.remove()
+    rec["multi/time_x"], rec["multi/prob"], rec["multi/window_softmax"] = np.asarray(time_x), np.asarray(prob, dtype=np.float64), np.stack(seen)
+    rec["multi/cfg"] = np.array([SHOT2, SRT2, END2, CLIP, CLIP, DIST, 1])
+    print("multi curve", len(time_x), "windows", len(seen), "p range", np.stack(seen)[:, 0].min(), np.stack(seen)[:, 0].max())
     # ---- smoothing ---------------------------------------------------------------------------------------------------------------
     x = np.random.RandomState(5).rand(64) * 1.4 - 0.2
     rec["smooth/x"] = x

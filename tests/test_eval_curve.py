@@ -98,6 +98,64 @@ def test_threshold_rule_matches_the_reference(gold):
     assert seen == 2
 
 
+def test_dataset_for_video_clip_table_and_preprocessing_match_the_reference(gold):
+    """src/dataset.py:80-144 (augmentation off): which frames a training clip reads, its label, crop / mean / transpose."""
+    from oracle import preprocess as op
+    tip, srt, L, dist, crop = [int(v) for v in gold["dsv/cfg"]]
+    idx, lab = op.clip_table(tip, srt, L, dist)
+    assert len(idx) == int(gold["dsv/n"]) and np.array_equal(lab, gold["dsv/labels"]) and lab[-1] == 0 and set(lab[:-1]) == {1}
+    frames = pc.synth_frames(_cfg(gold)[4], _cfg(gold)[5])
+    for i in (0, len(idx) - 1):
+        clip = op.video_clip(frames[idx[i] + 1: idx[i] + L + 1], crop)
+        assert np.array_equal(_sub(torch.from_numpy(clip)), gold["dsv/clip%d" % i])
+
+
+MULTI_AV = dict(image_size=128, patch_size=16, dim=16, depth=1, n_heads=2, in_channels=3, d_head=8, dropout=0.0, embedd_dropout=0.0,
+                scale_dim=2, pool="mean")
+MULTI_A0 = dict(n_features=len(TS_COLS), kernel_size=3, feature_dims=16, n_layers=1, n_heads=2, dim_feedforward=24, dropout=0.0)
+
+
+def _multi_inputs(gold):
+    from sklearn.preprocessing import RobustScaler
+    shot, srt, end, vl, tl, dist, tau = [int(v) for v in gold["multi/cfg"]]
+    g = np.random.RandomState(_cfg(gold)[5])
+    vals = (np.cumsum(g.standard_normal((120, len(TS_COLS))).astype(np.float32) * 0.3, axis=0)
+            + g.standard_normal(len(TS_COLS)).astype(np.float32)).astype(np.float32)
+    # the table is written with %.9g and read back as float32: identical values
+    t2 = np.arange(120) * (4.0 / 210)
+    t2 = np.array([float("%.9f" % v) for v in t2])
+    scaled = np.ascontiguousarray(RobustScaler().fit_transform(vals), dtype=np.float32)
+    return (shot, srt, end, vl, tl, dist, tau), t2, vals, scaled
+
+
+def test_multi_window_matching_and_curve_assembly_match_the_reference(gold):
+    from oracle import multimodal as om
+    from src.utils import prob_curve as npc
+    (shot, srt, end, vl, tl, dist, tau), t2, vals, scaled = _multi_inputs(gold)
+    nfr, seed = _cfg(gold)[4], _cfg(gold)[5]
+    ref = gold["multi/window_softmax"]
+    for mod in (pc, npc):
+        frames_of, ts_sel = mod.multi_window_tables(nfr, t2, srt, end, 0.3, 1.1, vl, tl, 4.0 / 210, tau)
+        assert len(frames_of) == len(ts_sel) == len(ref)
+        tx, q = mod.assemble_multi_curve(ref[:, 0].tolist(), t2[ts_sel[0]], t2[ts_sel[-1]], tau)
+        assert np.allclose(tx, gold["multi/time_x"], rtol=0, atol=1e-12) and len(q) == len(tx) and np.all((q >= 0) & (q <= 1))
+    assert np.array_equal(gold["multi/prob"], ref[:, 0].astype(np.float64))          # the reference returns the raw list
+    # the oracle's fused model on the oracle's windows reproduces the reference's per-window softmax
+    sd = {k[len("multi/sd/"):]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("multi/sd/")}
+    frames = pc.synth_frames(nfr, seed)
+    old_v, old_t = dict(om.VIDEO), dict(om.TS)
+    om.VIDEO.update(patch_size=16, depth=1, n_heads=2); om.TS.update(n_layers=1, n_heads=2, kernel_size=3)
+    try:
+        for i in (0, len(ref) - 1):
+            clip = pc.video_windows(frames[frames_of[i][0] - 1:], vl, 0, 0, 10 ** 6, 128)        # window 0 of the shifted stack
+            x_vis = torch.from_numpy(next(clip))[None]
+            x_ts = torch.from_numpy(pc.multi_ts_window(scaled, ts_sel[i], tl, tau))[None]
+            sm = torch.softmax(om.multimodal_forward(x_vis, x_ts, {k: v.clone() for k, v in sd.items()}, "mean", training=False), 1)[0]
+            assert np.abs(sm.numpy() - ref[i]).max() <= 2e-5, (i, sm, ref[i])
+    finally:
+        om.VIDEO.clear(); om.VIDEO.update(old_v); om.TS.clear(); om.TS.update(old_t)
+
+
 # ------------------------------------------------------------------------------------------------------------------------------
 def _native_classifier(gold, tag, T, S, seed):
     from src.models.R2Plus1D import R2Plus1DClassifier
@@ -196,3 +254,30 @@ def test_measure_computation_time_is_synchronised(gold):
     model = _native_classifier(gold, "eval", 4, 32, 9)
     mean, std, ts = measure_computation_time(model, (1, 3, 4, 32, 32), 5, "cuda:0")
     assert len(ts) == 5 and mean > 0 and all(t > 0 for t in ts)
+
+
+@pytest.mark.gpu
+def test_multi_probability_curve_on_gpu_matches_the_reference(gold, tmp_path):
+    from src.models.MultiModal import MultiModalModel
+    from src.utils import prob_curve as npc
+    (shot, srt, end, vl, tl, dist, tau), t2, vals, scaled = _multi_inputs(gold)
+    nfr, seed = _cfg(gold)[4], _cfg(gold)[5]
+    m = MultiModalModel(2, dict(MULTI_AV, n_frames=vl), dict(MULTI_A0, max_len=tl))
+    m.load_state_dict({k[len("multi/sd/"):]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("multi/sd/")}, strict=True)
+    for mod in m.modules():
+        if type(mod).__name__ == "NoiseLayer":
+            mod.std = 0.0
+    shot_csv, ts_csv = str(tmp_path / "shots.csv"), str(tmp_path / "ts.csv")
+    with open(shot_csv, "w", encoding="euc-kr") as f:
+        f.write("shot,tTQend,tftsrt,tipminf,frame_startup,frame_cutoff\n%d,1.05,0.3,1.1,%d,%d\n" % (shot, srt, end))
+    with open(ts_csv, "w") as f:
+        f.write("time,shot," + ",".join(TS_COLS) + "\n")
+        for i in range(120):
+            f.write("%.9f,%d," % (i * (4.0 / 210), shot) + ",".join("%.9g" % v for v in vals[i]) + "\n")
+    frames = torch.from_numpy(pc.synth_frames(nfr, seed)).cuda()
+    ref = gold["multi/window_softmax"][:, 0]
+    for w in (1, 16):
+        t, p = npc.generate_prob_curve_from_multi(None, m, "cuda:0", None, ts_csv, TS_COLS, shot_csv, shot, vl, tl, dist, 4.0 / 210,
+                                                  None, tau, frames=frames, windows_per_launch=w)
+        assert np.allclose(t, gold["multi/time_x"], rtol=0, atol=1e-12)
+        assert len(p) == len(ref) and np.abs(np.asarray(p) - ref).max() <= 1e-3, np.abs(np.asarray(p) - ref).max()

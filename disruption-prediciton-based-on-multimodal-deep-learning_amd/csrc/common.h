@@ -69,7 +69,7 @@ int patch_launch(const PatchPlan* p, const float* src, const float* ps, const fl
 bool patch_can_fuse(const PatchPlan* p);
 
 struct WgradPlan;
-const WgradPlan* wgrad_lookup(const MdConvDesc* d);
+const WgradPlan* wgrad_lookup(const MdConvDesc* d, int xpitch = 0, int xc0 = 0, int dw_cin = 0);   // xpitch != 0: X = channel slice of a wider tensor
 size_t wgrad_patch_workspace_floats(const WgradPlan* p);
 int wgrad_patch_launch(const WgradPlan* p, const MdConvDesc* d, const float* src, const float* ps, const float* psh,
                        float slope, const float* dy, float* dw, float* slab, hipStream_t s, int ysplit = 0);

@@ -563,6 +563,22 @@ extern "C" int md_conv_dgrad_fmt(const MdConvDesc* d, const void* dy, int dy_spl
   bw.slope = y_view->slope;
   return patch_launch(pp, (const float*)dy, nullptr, nullptr, 1.f, wpack_dgrad, dx, partial, acc, (hipStream_t)stream, &bw);
 }
+
+// Wide Linears (1x1x1, unit stride, more source channels than the LDS-patch weight-gradient kernel stages at once: ViViT's patch
+// embedding 768 -> 128 and FeedForward 1024 -> 128): the weight gradient is independent per source channel, so it is computed
+// slice by slice of <= 256 channels with the same split-precision kernel reading a channel slice of the rows.
+#define WIDE_CHUNK 256
+static bool wide_linear_chunks(const MdConvDesc* d) {
+  static const int off = getenv("MD_WIDE_WGRAD") && atoi(getenv("MD_WIDE_WGRAD")) == 0;
+  return !off && d->kt == 1 && d->kh == 1 && d->kw == 1 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 && d->ph == 0 && d->pw == 0 &&
+         md_cpad(d->Cin) > 320;      // PMAXC of the patch kernels (exact-fp32 mode: wgrad_lookup declines, the gather kernel runs)
+}
+static const WgradPlan* wide_chunk_plan(const MdConvDesc* d, int c0) {
+  MdConvDesc dc = *d;
+  dc.Cin = d->Cin - c0 < WIDE_CHUNK ? d->Cin - c0 : WIDE_CHUNK;
+  return wgrad_lookup(&dc, md_cpad(d->Cin), c0, d->Cin);
+}
+
 extern "C" int md_conv_wgrad_fmt(const MdConvDesc* d, const MdActView* x, const void* dy, int dy_split, float* dw,
                                  float* workspace, void* stream) {
   if (!dy_split) return md_conv_wgrad(d, x, (const float*)dy, dw, workspace, stream);
@@ -578,6 +594,16 @@ extern "C" int md_conv_wgrad_fmt(const MdConvDesc* d, const MdActView* x, const 
 extern "C" size_t md_conv_wgrad_workspace_floats(const MdConvDesc* d) {
   if (check_desc(d) != MD_OK) return 0;
   if (const WgradPlan* wp = wgrad_lookup(d)) return wgrad_patch_workspace_floats(wp);
+  if (wide_linear_chunks(d)) {
+    size_t need = 0;
+    for (int c0 = 0; c0 < d->Cin; c0 += WIDE_CHUNK) {
+      const WgradPlan* wp = wide_chunk_plan(d, c0);
+      if (!wp) return 0;
+      const size_t n = wgrad_patch_workspace_floats(wp);
+      if (n > need) need = n;
+    }
+    return need;
+  }
   return 0;
 }
 
@@ -589,6 +615,19 @@ extern "C" int md_conv_wgrad(const MdConvDesc* d, const MdActView* x, const floa
   if (const WgradPlan* wp = wgrad_lookup(d)) {
     if (!workspace) return MD_ERR_WORKSPACE;
     return wgrad_patch_launch(wp, d, x->data, x->scale, x->shift, x->slope, dy_raw, dw, workspace, (hipStream_t)stream);
+  }
+  if (wide_linear_chunks(d) && workspace) {
+    bool all = true;
+    for (int c0 = 0; c0 < d->Cin && all; c0 += WIDE_CHUNK) all = wide_chunk_plan(d, c0) != nullptr;
+    if (all) {
+      for (int c0 = 0; c0 < d->Cin; c0 += WIDE_CHUNK) {
+        MdConvDesc dc = *d;
+        dc.Cin = d->Cin - c0 < WIDE_CHUNK ? d->Cin - c0 : WIDE_CHUNK;
+        rc = wgrad_patch_launch(wide_chunk_plan(d, c0), &dc, x->data, x->scale, x->shift, x->slope, dy_raw, dw, workspace, (hipStream_t)stream);
+        if (rc != MD_OK) return rc;
+      }
+      return MD_OK;
+    }
   }
   Geom g = geom_fwd(d);
   const int taps = d->kt * d->kh * d->kw;

@@ -915,6 +915,9 @@ struct WGeom {
   int pack2, pk_shift, pk_kw;   // pixel-pair reinterpretation (see wgrad_build); then kw = k-tiles per filter row
   int tapw;                     // X patch bytes between successive values of the kw index
   unsigned x_bytes, y_bytes;    // tensor sizes for the buffer descriptors (< 2 GiB)
+  int xpitch, xc0;              // floats per X pixel in memory and first channel read (a channel slice of a wider tensor: the
+                                // chunked weight gradient of wide Linears; = Cpi, 0 otherwise)
+  int dw_cin, dw_c0;            // the dW tensor's full Cin and the slice's first channel
 };
 
 __device__ __forceinline__ bf16x8 tr_read2(const char* p0, const char* p1) {
@@ -948,7 +951,7 @@ __global__ __launch_bounds__(256) void k_wgrad_patch(
   const int n0 = ng * g.nrep * 16;              // first dY channel of this workgroup
   const int kt0 = (kg * 4 + wave) * g.ktw;      // first k-tile of this wave
   const bool prologue = pscale != nullptr;
-  if (prologue) for (int c = t; c < g.Cpi; c += 256) { const int cs = g.pack2 ? (c & 3) : c; sScale[c] = pscale[cs]; sShift[c] = pshift[cs]; }
+  if (prologue) for (int c = t; c < g.Cpi; c += 256) { const int cs = g.pack2 ? (c & 3) : g.xc0 + c; sScale[c] = pscale[cs]; sShift[c] = pshift[cs]; }
 
   f32x4 acc[KTW][NREP];
 #pragma unroll
@@ -999,8 +1002,8 @@ __global__ __launch_bounds__(256) void k_wgrad_patch(
       sGY[t] = ri.y;
     }
     __syncthreads();
-    if (!(dbg & 1)) stage_image_ptr<false>(src, g.Cpi, 0, g.Cpi >> 2, sG, g.P, g.C8i, g.magicC8, sP, g.ppitch, g.lo_off, prologue, sScale, sShift,
-                pslope, t);
+    if (!(dbg & 1)) stage_image_ptr<false>(src, g.xpitch, g.xc0, g.Cpi >> 2, sG, g.P, g.C8i, g.magicC8, sP, g.ppitch, g.lo_off, prologue, sScale - g.xc0,
+                sShift - g.xc0, pslope, t);
     if (!(dbg & 2)) stage_image_ptr<false>(dy, g.Cpo, n0, ycv4, sGY, PM, g.NC, g.magicNC, sY, g.ypitch, g.ylo_off, false, nullptr, nullptr, 1.f, t,
                                            ysplit ? (g.Cpo >> 3) : 0);
     __syncthreads();
@@ -1089,7 +1092,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void k_wgrad_patch_pf(
   const int n0 = ng * g.nrep * 16;
   const int kt0 = (kg * 4 + wave) * g.ktw;
   const bool prologue = pscale != nullptr;
-  if (prologue) for (int c = t; c < g.Cpi; c += NT) { const int cs = g.pack2 ? (c & 3) : c; sScale[c] = pscale[cs]; sShift[c] = pshift[cs]; }
+  if (prologue) for (int c = t; c < g.Cpi; c += NT) { const int cs = g.pack2 ? (c & 3) : g.xc0 + c; sScale[c] = pscale[cs]; sShift[c] = pshift[cs]; }
   if (t < PM) {
     const int rt = t / g.byx; const int r = t - rt * g.byx;
     const int ry = r / g.bx; const int rx = r - ry * g.bx;
@@ -1133,7 +1136,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void k_wgrad_patch_pf(
       const int ppy = r / g.px; const int ppx = r - ppy * g.px;
       xloc[u] = ppt | (ppy << 6) | (ppx << 15) | (c8 << 24);
       xdst[u] = pixel * g.ppitch + c8 * 16;
-      xrel[u] = ((ppt * g.Hi + ppy) * g.Wi + ppx) * g.Cpi + c8 * 8;
+      xrel[u] = ((ppt * g.Hi + ppy) * g.Wi + ppx) * g.xpitch + g.xc0 + c8 * 8;
     }
   }
 #pragma unroll
@@ -1163,7 +1166,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void k_wgrad_patch_pf(
     const int tb = b % g.nbt; const int n = b / g.nbt;
     q_t0 = tb * g.bt; q_y0 = yb * g.by; q_x0 = xb * g.bx;
     q_ot = q_t0 * g.st + g.org_t; q_oh = q_y0 * g.sh + g.org_h; q_ow = q_x0 * g.sw + g.org_w;
-    q_xbase = (((n * g.Ti + q_ot) * g.Hi + q_oh) * g.Wi + q_ow) * g.Cpi;
+    q_xbase = (((n * g.Ti + q_ot) * g.Hi + q_oh) * g.Wi + q_ow) * g.xpitch;
     q_ybase = (((n * g.To + q_t0) * g.Ho + q_y0) * g.Wo + q_x0) * g.Cpo;
     q_live = live ? 1 : 0;
   };
@@ -1309,7 +1312,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void k_wgrad_patch_pf(
 // pack2: k-tile kt = (filter row, txg), row i of the tile = real tap dx = 4 txg + (i >> 2) + shift, channel i & 3.
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slab, int nslices, int nkt, int KT, int N16,
                                                       int Cout, int Cin, int taps, float* __restrict__ dw, int pack2,
-                                                      int kwt, int kw_real, int shift, int taps_real) {
+                                                      int kwt, int kw_real, int shift, int taps_real, int dw_cin, int dw_c0) {
   __shared__ float red[4][64];
   const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int idx = blockIdx.x * 64 + o;                         // over [k16 rows][N16], cout fastest
@@ -1338,14 +1341,16 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
       if (co < Cout && c < Cin && dx >= 0 && dx < kw_real) dw[((size_t)co * Cin + c) * taps_real + row * kw_real + dx] = s;
     } else {
       const int tap = kt / KT; const int c = (kt - tap * KT) * 16 + (krow & 15);
-      if (co < Cout && c < Cin) dw[((size_t)co * Cin + c) * taps + tap] = s;
+      if (co < Cout && c < Cin) dw[((size_t)co * dw_cin + dw_c0 + c) * taps + tap] = s;
     }
   }
 }
 
 struct WgradPlan { WGeom g; size_t lds; int nslices; bool w8; };
 
-static bool wgrad_build(const MdConvDesc* d, WGeom* out, size_t* lds_bytes, int* nslices) {
+// xpitch / xc0: X is the channel slice [xc0, xc0 + Cin) of a tensor with xpitch floats per pixel (0: X is the whole tensor);
+// dW then goes to columns [xc0, xc0 + Cin) of a (Cout, dw_cin, taps) tensor
+static bool wgrad_build(const MdConvDesc* d, WGeom* out, size_t* lds_bytes, int* nslices, int xpitch = 0, int xc0 = 0, int dw_cin = 0) {
   WGeom g;
   g.st = d->st; g.sh = d->sh; g.sw = d->sw;
   g.Ti = d->Ti; g.Hi = d->Hi; g.Wi = d->Wi; g.Cpi = md_cpad(d->Cin);
@@ -1386,7 +1391,10 @@ static bool wgrad_build(const MdConvDesc* d, WGeom* out, size_t* lds_bytes, int*
   g.magicNC = g.NC == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)g.NC) + 1u;
   if (g.Cpi > PMAXC) return false;
   {
-    const unsigned long long xb = (unsigned long long)d->N * g.Ti * g.Hi * g.Wi * g.Cpi * 4ull;
+    g.xpitch = xpitch ? xpitch : g.Cpi; g.xc0 = xpitch ? xc0 : 0;
+    g.dw_cin = xpitch ? dw_cin : d->Cin; g.dw_c0 = xpitch ? xc0 : 0;
+    if (xpitch && g.pack2) return false;
+    const unsigned long long xb = (unsigned long long)d->N * g.Ti * g.Hi * g.Wi * g.xpitch * 4ull;
     const unsigned long long yb = (unsigned long long)d->N * g.To * g.Ho * g.Wo * g.Cpo * 4ull;
     g.x_bytes = xb < 0x80000000ull ? (unsigned)xb : 0u; g.y_bytes = yb < 0x80000000ull ? (unsigned)yb : 0u;   // 0: no buffer addressing
   }
@@ -1460,20 +1468,20 @@ static int wgrad_wgs_per_cu(const WGeom& g, size_t lds) {
   return nb > 2 ? 2 : nb;
 }
 
-const WgradPlan* wgrad_lookup(const MdConvDesc* d) {
+const WgradPlan* wgrad_lookup(const MdConvDesc* d, int xpitch, int xc0, int dw_cin) {
   if (g_exact_fp32.load()) return nullptr;
   static const int dis = getenv("MD_PATCH_WGRAD") && atoi(getenv("MD_PATCH_WGRAD")) == 0;
   if (dis) return nullptr;
   static std::mutex mu;
-  static std::map<std::array<int, 18>, WgradPlan*> cache;
-  std::array<int, 18> key = {d->N, d->Ti, d->Hi, d->Wi, d->Cin, d->To, d->Ho, d->Wo, d->Cout, d->kt, d->kh, d->kw,
-                             d->st, d->sh, d->sw, d->pt, d->ph, d->pw};
+  static std::map<std::array<int, 21>, WgradPlan*> cache;
+  std::array<int, 21> key = {d->N, d->Ti, d->Hi, d->Wi, d->Cin, d->To, d->Ho, d->Wo, d->Cout, d->kt, d->kh, d->kw,
+                             d->st, d->sh, d->sw, d->pt, d->ph, d->pw, xpitch, xc0, dw_cin};
   std::lock_guard<std::mutex> lock(mu);
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
   WgradPlan* wp = nullptr;
   WGeom g; size_t lds = 0; int ns = 0;
-  if (wgrad_build(d, &g, &lds, &ns)) {
+  if (wgrad_build(d, &g, &lds, &ns, xpitch, xc0, dw_cin)) {
     // one slice (= one slab of partial sums) per resident workgroup: a single full round on the chip, and no more
     // slab traffic than that needs
     // CUs to occupy.  The executor runs weight gradients on a side stream next to the BatchNorm-backward / data-gradient
@@ -1542,7 +1550,7 @@ int wgrad_patch_launch(const WgradPlan* p, const MdConvDesc* d, const float* src
   MD_CHECK_LAUNCH();
   const int total = g.nkt * 16 * g.N16;
   MD_KLAUNCH(k_wgrad_reduce, dim3(md_cdiv(total, 64)), dim3(256), 0, s, slab, p->nslices, g.nkt, g.KT, g.N16, d->Cout,
-             d->Cin, g.taps, dw, g.pack2, g.kw, g.pk_kw, g.pk_shift, d->kt * d->kh * d->kw);
+             d->Cin, g.taps, dw, g.pack2, g.kw, g.pk_kw, g.pk_shift, d->kt * d->kh * d->kw, g.dw_cin, g.dw_c0);
   MD_CHECK_LAUNCH();
   return MD_OK;
 }

@@ -102,6 +102,9 @@ SIGNATURES = {
     "md_maxpool_1x3x3_bwd": (C.c_int, [_P, _P, C.c_int64, _I32, _I32, _P, _P]),
     "md_rowmean_fwd": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P]),
     "md_rowmean_bwd": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P]),
+    "md_patch_embed_fwd": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I32, _P, _P, _P, _P, _I32, _P, _P]),
+    "md_patch_embed_wgrad_workspace_floats": (_SZ, [_I32, _I32, _I32, _I32, _I32, _I32, _I32]),
+    "md_patch_embed_wgrad": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I32, _P, _I32, _P, _P, _P]),
     "md_channel_bias_fwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P]),
     "md_channel_bias_bwd": (C.c_int, [_P, _I32, _I32, _I32, _P, _P, _P]),
     "md_channel_bias_bwd_scratch_floats": (_SZ, [_I32, _I32, _I32]),

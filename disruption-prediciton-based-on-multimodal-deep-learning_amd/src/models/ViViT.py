@@ -18,8 +18,8 @@ from typing import Union
 import torch
 import torch.nn as nn
 
-from ._unit import (AddLayerNormFunction, AttentionFunction, EluFunction, GeluFunction, ResidualLayerNormFunction, _ChannelBias,
-                    _SeqSum, dropout, linear_wb)
+from ._unit import (AddLayerNormFunction, AttentionFunction, EluFunction, GeluFunction, PatchEmbedFunction, ResidualLayerNormFunction,
+                    _ChannelBias, _SeqSum, dropout, linear_wb)
 
 
 def _layer_norm(x, norm: nn.LayerNorm):
@@ -175,21 +175,36 @@ class _ViViTBase(nn.Module):
     def _encode(self, x: torch.Tensor):
         if x.size()[1] == self.in_channels:
             x = torch.permute(x, (0, 2, 1, 3, 4))
-        patches = self.to_patch_embedding[0](x)
-        b, t, n, _ = patches.shape
+        b, t, c, H, W = x.shape
+        p = self.to_patch_embedding[0].p
+        lin = self.to_patch_embedding[1]
         d = self.dim
-        x = _rows(patches, self.to_patch_embedding[1])                              # (b, t, n, d)
-        x = _with_token(x.reshape(b * t, n, d), self.space_token)                   # (b t, n+1, d)
+        n = (H // p) * (W // p)
         pos = self.pos_embedding[0, :, :(n + 1)]
         if pos.shape[0] != t:
             raise RuntimeError("ViViT: the clip has %d frames, the positional table %d" % (t, pos.shape[0]))
-        x = _ChannelBias.apply(x.reshape(b, t * (n + 1) * d, 1), pos.reshape(-1)).reshape(b * t, n + 1, d)
+        if self._fused_patch_embed(x, p, d):
+            # one gather-GEMM: patches are read straight from the clip, bias + space token + positional table in the epilogue
+            w_perm = lin.weight.view(d, p, p, c).permute(0, 3, 1, 2).reshape(d, c * p * p)         # columns (p1 p2 c) -> (c p1 p2)
+            x = PatchEmbedFunction.apply(x, w_perm, lin.bias, pos.contiguous(), self.space_token.reshape(d), p)
+        else:
+            patches = self.to_patch_embedding[0](x)
+            x = _rows(patches, lin)                                                     # (b, t, n, d)
+            x = _with_token(x.reshape(b * t, n, d), self.space_token)                   # (b t, n+1, d)
+            x = _ChannelBias.apply(x.reshape(b, t * (n + 1) * d, 1), pos.reshape(-1)).reshape(b * t, n + 1, d)
         x = dropout(x, self.dropout.p, self.dropout.training)
         x = self.space_transformer(x)
         x = x[:, 0].reshape(b, t, d)
         x = _with_token(x, self.temporal_token)                                     # (b, t+1, d)
         x = self.temporal_transformer(x)
         return _SeqSum.apply(x, 1.0 / (t + 1)) if self.pool == 'mean' else x[:, 0]
+
+    @staticmethod
+    def _fused_patch_embed(x, p: int, d: int) -> bool:
+        from .. import _native as N
+        ok_geo = p >= 8 and (p & (p - 1)) == 0 and x.shape[4] % 4 == 0 and all(s % 4 == 0 for s in x.stride()[:3])
+        return (ok_geo and x.stride(4) == 1 and x.stride(3) == x.shape[4] and d % 4 == 0 and d <= 128 and x.dtype == torch.float32
+                and not N.lib().md_get_exact_fp32())
 
     def summary(self, *args, **kwargs):
         rows = ["%-60s %-20s %d" % (k, tuple(v.shape), v.numel()) for k, v in self.named_parameters()]

@@ -329,6 +329,58 @@ class _ChannelBias(torch.autograd.Function):
         return g, db
 
 
+class PatchEmbedFunction(torch.autograd.Function):
+    """ViViT's patch embedding + space token + positional table as one gather-GEMM (md_patch_embed_*; reference ViViT.py:141-148,
+    175-184).  x: the clip as a (b, t, c, H, W) tensor or view with contiguous image rows (read in place through its strides);
+    w_perm (dim, c*p*p): the Linear weight with columns in (c, p1, p2) order; pos (t, n+1, dim); token (dim).
+    Returns (b*t, n+1, dim).  The clip's own gradient is only produced when asked for (it is the model input: training never
+    asks): patch gradients from the MFMA Linear, scattered back with a view permutation."""
+    @staticmethod
+    def forward(ctx, x, w_perm, bias, pos, token, patch):
+        ops.require_cuda(w_perm, bias, pos, token)
+        if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 5 or x.stride(4) != 1 or x.stride(3) != x.shape[4]:
+            raise RuntimeError("mi355x hot path: patch embedding expects a CUDA fp32 (b, t, c, H, W) clip with contiguous image rows")
+        b, t, c, H, W = x.shape
+        dim = w_perm.shape[0]
+        n = (H // patch) * (W // patch)
+        out = torch.empty((b * t, n + 1, dim), device=x.device, dtype=torch.float32)
+        geo = (b, t, c, H, W, x.stride(0), x.stride(1), x.stride(2), int(patch))
+        N.check(N.lib().md_patch_embed_fwd(C.c_void_p(x.data_ptr()), b, t, c, H, W, x.stride(0), x.stride(1), x.stride(2), int(patch),
+                                           ops._p(w_perm), ops._p(bias), ops._p(pos), ops._p(token), dim, ops._p(out), ops._stream()),
+                "md_patch_embed_fwd")
+        ctx.geo, ctx.dim, ctx.n = geo, dim, n
+        ctx.save_for_backward(x, w_perm)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w_perm = ctx.saved_tensors
+        b, t, c, H, W, sb, st, sc, patch = ctx.geo
+        dim, n = ctx.dim, ctx.n
+        g = ops.f32(dout).contiguous()                                          # (b*t, n+1, dim)
+        L = N.lib()
+        dw = torch.empty((dim, c * patch * patch), device=g.device, dtype=torch.float32)
+        ws = torch.empty(L.md_patch_embed_wgrad_workspace_floats(b, t, c, H, W, patch, dim), device=g.device, dtype=torch.float32)
+        N.check(L.md_patch_embed_wgrad(C.c_void_p(x.data_ptr()), b, t, c, H, W, sb, st, sc, patch, ops._p(g), dim, ops._p(dw), ops._p(ws),
+                                       ops._stream()), "md_patch_embed_wgrad")
+        # positional table: column sums over the batch (fixed-order two-level reduction); bias and token follow from it
+        Cc = t * (n + 1) * dim
+        dpos = torch.empty(Cc, device=g.device, dtype=torch.float32)
+        ns = L.md_channel_bias_bwd_scratch_floats(b, Cc, 1)
+        scratch = torch.empty(ns, device=g.device) if ns else None
+        N.check(L.md_channel_bias_bwd(ops._p(g), b, Cc, 1, ops._p(dpos), ops._p(scratch), ops._stream()), "md_channel_bias_bwd")
+        dpos = dpos.view(t, n + 1, dim)
+        dbias = dpos[:, 1:].sum(dim=(0, 1))
+        dtoken = dpos[:, 0].sum(dim=0)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            with torch.no_grad():
+                dp = LinearRowsFunction.apply(g[:, 1:].reshape(b * t * n, dim), w_perm.t().contiguous())      # (M, c*p*p), columns (c p1 p2)
+            nh, nw = H // patch, W // patch
+            dx = dp.view(b, t, nh, nw, c, patch, patch).permute(0, 1, 4, 2, 5, 3, 6).reshape(b, t, c, H, W)
+        return dx, dw, dbias, dpos, dtoken, None
+
+
 class _SeqSum(torch.autograd.Function):
     """scale * sum over the sequence axis of x (B, S, D)   (md_seq_sum_*): the closed form of the reference's attention
     pooling (see models/CnnLSTM.py); extra parameters passed in get exact zero gradients."""

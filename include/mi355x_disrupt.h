@@ -246,6 +246,20 @@ int md_maxpool_1x3x3_bwd(const float* dout, const int32_t* idx, int64_t planes, 
 int md_rowmean_fwd(const float* x, int64_t rows, int64_t thw, float* mean, void* stream);
 int md_rowmean_bwd(const float* dmean, int64_t rows, int64_t thw, float* dx, void* stream);
 
+/* ViViT's tubelet / patch embedding (reference src/models/ViViT.py:141-148 'b t c (h p1) (w p2) -> b t (h w) (p1 p2 c)' + Linear,
+ * :175-184 space token + positional table) as one gather-GEMM: out [B*T][n+1][dim], row 0 = token + pos[t][0], row 1+j =
+ * patch_j . W'^T + bias + pos[t][1+j].  The clip is read in place through strides (floats) sb / st / sc of (b, t, c); rows of
+ * W pixels contiguous.  w_perm [dim][C*p*p] is the Linear weight with its columns in (c, p1, p2) order (the reference's are
+ * (p1, p2, c)); pos [T][n+1][dim].  patch: power of two >= 8.  MD_ERR_UNSUPPORTED in exact-fp32 mode (callers compose the
+ * embedding from md_conv_fwd + md_channel_bias_*).  The weight gradient dw_perm [dim][C*p*p] (same column order) gathers the
+ * patches again instead of keeping a rearranged copy; gout is the gradient of `out` (all n+1 rows per frame). */
+int md_patch_embed_fwd(const float* x, int32_t B, int32_t T, int32_t C, int32_t H, int32_t W, int64_t sb, int64_t st, int64_t sc,
+                       int32_t patch, const float* w_perm, const float* bias, const float* pos, const float* token, int32_t dim,
+                       float* out, void* stream);
+size_t md_patch_embed_wgrad_workspace_floats(int32_t B, int32_t T, int32_t C, int32_t H, int32_t W, int32_t patch, int32_t dim);
+int md_patch_embed_wgrad(const float* x, int32_t B, int32_t T, int32_t C, int32_t H, int32_t W, int64_t sb, int64_t st, int64_t sc,
+                         int32_t patch, const float* gout, int32_t dim, float* dw_perm, float* workspace, void* stream);
+
 /* Per-channel bias on an (N,C,L) tensor (a Conv1d bias that is not absorbed by a following normalisation,
  * src/models/CnnLSTM.py:42) and its gradient db[c] = sum_{n,l} dout. */
 int md_channel_bias_fwd(const float* x, const float* bias, int32_t N, int32_t C, int32_t L, float* out, void* stream);

@@ -205,3 +205,39 @@ def test_residule_prenorm_feedforward_modules_standalone():
     assert float((xg.grad.cpu() - xr.grad).abs().max()) < 5e-5
     for k, p in blk.named_parameters():
         assert float((p.grad.cpu() - ref_grads[k]).abs().max()) <= 1e-4 * max(1.0, float(ref_grads[k].abs().max())), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,t,c,S,p,dim,perm", [(2, 3, 3, 224, 16, 128, True), (1, 2, 3, 64, 8, 48, False), (2, 2, 1, 32, 32, 20, True)])
+def test_fused_patch_embedding_matches_fp64(b, t, c, S, p, dim, perm):
+    """md_patch_embed_* (gather-GEMM with bias, space token and positional table in the epilogue; weight gradient that gathers the
+    patches again) against the reference's formulation in fp64 -- 'b t c (h p1) (w p2) -> b t (h w) (p1 p2 c)', Linear, token
+    concatenation, positional add (ViViT.py:141-148, 175-184) -- at the cfg3 geometry and two others, on a (b,t,c,H,W) clip and
+    on the permuted view of a (b,c,t,H,W) clip (read in place): output 2e-5, every gradient 3e-5 relative L2."""
+    from src.models._unit import PatchEmbedFunction
+    torch.manual_seed(b * 100 + p)
+    n = (S // p) ** 2
+    clip = torch.randn(b, c, t, S, S) * 40 if perm else torch.randn(b, t, c, S, S) * 40
+    w = torch.randn(dim, p * p * c) / (p * p * c) ** 0.5 / 40; bias = torch.randn(dim); pos = torch.randn(t, n + 1, dim); tok = torch.randn(dim)
+    gout = torch.randn(b * t, n + 1, dim)
+    # fp64 reference, the reference's own order of operations
+    x64 = (clip.permute(0, 2, 1, 3, 4) if perm else clip).double().requires_grad_(True)
+    w64, b64, p64, t64 = (v.double().requires_grad_(True) for v in (w, bias, pos, tok))
+    patches = x64.reshape(b, t, c, S // p, p, S // p, p).permute(0, 1, 3, 5, 4, 6, 2).reshape(b, t, n, p * p * c)
+    e = patches @ w64.t() + b64
+    e = torch.cat((t64.view(1, 1, 1, dim).expand(b, t, 1, dim), e), dim=2) + p64.unsqueeze(0)
+    ref = e.reshape(b * t, n + 1, dim)
+    ref.backward(gout.double())
+    xg = clip.cuda().requires_grad_(True)
+    wg, bg, pg, tg = (v.cuda().requires_grad_(True) for v in (w, bias, pos, tok))
+    xin = xg.permute(0, 2, 1, 3, 4) if perm else xg
+    w_perm = wg.view(dim, p, p, c).permute(0, 3, 1, 2).reshape(dim, c * p * p)
+    out = PatchEmbedFunction.apply(xin, w_perm, bg, pg, tg, p)
+    out.backward(gout.cuda())
+    torch.cuda.synchronize()
+    rel = lambda a, r: float((a.double().cpu() - r).norm() / r.norm())
+    assert rel(out.detach(), ref.detach()) < 2e-5
+    gx64 = x64.grad.permute(0, 2, 1, 3, 4) if perm else x64.grad
+    for name, a, r in (("w", wg.grad, w64.grad), ("bias", bg.grad, b64.grad), ("pos", pg.grad, p64.grad), ("token", tg.grad, t64.grad),
+                       ("x", xg.grad, gx64)):
+        assert rel(a, r) < 3e-5, (name, rel(a, r))

@@ -69,10 +69,40 @@ for _ in range(steps):
     loss = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
 assert bool(torch.isfinite(loss))
-print(json.dumps({"metric": "clips/sec (full step) SlowFast + MLSTM_FCN, GradientBlending over LDAM + DRW weights", "value": round(B / dt, 1),
-                  "unit": "clips/s", "n_gpus": 1, "steps": steps, "warmup": 3, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True,
-                  "data": "synthetic", "loss": float(loss.detach()),
-                  "config": {"workload": f"BASELINE configs[4] on ONE GPU: SlowFast [1,2,2,1] alpha 4 ({B},3,32,224,224) + MLSTM_FCN (14x21, fcn 128, LSTM 128x4 bi), FusionGB, GradientBlending(0.1/0.4/0.5) over LDAM(max_m 0.5, s 1) with DRW weights (beta 0.75), ClipAdamW(2e-4, clip 1.0)"}}))
+def cpu_baseline(nsteps=2, warmup=1):
+    """oracle/fusion.py (SlowFast + MLSTM_FCN restatements, dropout off) forward + blended LDAM loss + backward on the host cores."""
+    from oracle import fusion as ofu, losses as ol
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    leaves = [v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running_" not in k]
+    xv_c, xt_c, y_c = xv.cpu(), xt.cpu(), y.cpu()
+    m_list = ol.ldam_margins(cls_num, 0.5)
+    wc = torch.tensor(w, dtype=torch.float32)
+    cfg = dict(kernel_size=3, stride=1, lstm_n_layers=4, bidirectional=True, alpha=0.01)
+    def cstep():
+        for v in leaves:
+            v.grad = None
+        o = ofu.slowfast_mlstm_forward(xv_c, xt_c, sd, [1, 2, 2, 1], 4, 1.0, cfg, True)
+        l = [ol.ldam_loss(t, y_c, m_list, wc, 1.0) for t in o]
+        ol.gradient_blending(l[0], l[1], l[2], 0.1, 0.4, 0.5).backward()
+    for _ in range(warmup):
+        cstep()
+    t0 = time.perf_counter()
+    for _ in range(nsteps):
+        cstep()
+    return {"value": round(B * nsteps / (time.perf_counter() - t0), 3), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{nsteps} forward+loss+backward steps (after {warmup} warm-up) of the same B={B} cfg5 workload, oracle/fusion.py on torch-CPU, no optimizer step"}
+
+
+gbs = B / dt * 686e6 / 1e9
+out = {"metric": "clips/sec (full step) SlowFast + MLSTM_FCN, GradientBlending over LDAM + DRW weights", "value": round(B / dt, 1),
+       "unit": "clips/s", "n_gpus": 1, "steps": steps, "warmup": 3, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True,
+       "data": "synthetic", "loss": float(loss.detach()), "dtype": "f32 storage; 3 fp16/bf16 MFMAs per product",
+       "config": {"workload": f"BASELINE configs[4] on ONE GPU: SlowFast [1,2,2,1] alpha 4 ({B},3,32,224,224) + MLSTM_FCN (14x21, fcn 128, LSTM 128x4 bi), FusionGB, GradientBlending(0.1/0.4/0.5) over LDAM(max_m 0.5, s 1) with DRW weights (beta 0.75), ClipAdamW(2e-4, clip 1.0)"},
+       "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "traffic": None,
+                    "kernel": "whole step: clips/s x 686 MB/clip (SURVEY 8(d): SlowFast conv I/O, fp32 storage, fwd+bwd) -- the composable path is host-bound, so this is a whole-job figure, not a kernel's"}}
+if not os.environ.get("NO_CPU_BASELINE"):
+    out["cpu_baseline"] = cpu_baseline()
+print(json.dumps(out))
 if os.environ.get("CFG5_PROFILE"):
     from torch.profiler import profile, ProfilerActivity
     with profile(activities=[ProfilerActivity.CUDA]) as prof:

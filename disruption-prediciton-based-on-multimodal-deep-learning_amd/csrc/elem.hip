@@ -513,6 +513,76 @@ extern "C" int md_clip_preprocess(const uint8_t* frames, int32_t B, int32_t T, i
 }
 
 
+// The six augmentations of DatasetForVideo.get_video_data (src/dataset.py:129-135, 152-227) between the crop and the mean
+// subtraction, decided on the host (src/utils/clip_preprocess.py::draw_augmentation, same random-number calls as the
+// reference) and applied here per output pixel: brightness (add + clip to [10,255], or add + horizontal flip), contrast
+// (cv2.convertScaleAbs: |alpha x| rounded half to even, saturated to 0..255), Gaussian blur (separable, row pass then column
+// pass in fp32, BORDER_REFLECT_101), the two edge masks the reference calls shifts.  par [B][10] int32: mode_b (0 none, 1 add+clip,
+// 2 add+flip), bright, contrast on, alpha, blur on, ksize, row_lo, row_hi, col_lo, col_hi.  gk: ksize Gaussian weights.
+__device__ __forceinline__ float aug_point(const unsigned char* fr, int Wr, int y0, int x0, int S, int yy, int xx, int c, int mode_b,
+                                           float bright, int contrast, float alpha) {
+  const int xs = mode_b == 2 ? S - 1 - xx : xx;
+  float v = (float)fr[((int64_t)(y0 + yy) * Wr + (x0 + xs)) * 3 + c];
+  if (mode_b == 1) v = fminf(fmaxf(__fadd_rn(v, bright), 10.f), 255.f);
+  else if (mode_b == 2) v = __fadd_rn(v, bright);
+  if (contrast) v = fminf(fmaxf(rintf(fabsf(__fmul_rn(v, alpha))), 0.f), 255.f);
+  return v;
+}
+__global__ __launch_bounds__(256) void k_clip_augment(const unsigned char* __restrict__ frames, int B, int T, int Hr, int Wr, int S,
+                                                     int y0, int x0, float m0, float m1, float m2, int layout,
+                                                     const int* __restrict__ par, const float* __restrict__ gk,
+                                                     float* __restrict__ out) {
+  const int64_t n = (int64_t)B * T * S * S;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const int x = (int)(e % S); int64_t r = e / S;
+    const int y = (int)(r % S); r /= S;
+    const int t = (int)(r % T), b = (int)(r / T);
+    const int* q = par + b * 10;
+    const int mode_b = q[0], contrast = q[2], blur = q[4], ks = q[5];
+    const float bright = (float)q[1], alpha = (float)q[3];
+    const unsigned char* fr = frames + ((int64_t)b * T + t) * Hr * Wr * 3;
+    float v[3] = {0.f, 0.f, 0.f};
+    if (y >= q[6] && y < q[7] && x >= q[8] && x < q[9]) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if (!blur) { v[c] = aug_point(fr, Wr, y0, x0, S, y, x, c, mode_b, bright, contrast, alpha); continue; }
+        const int h = ks >> 1;
+        float acc = 0.f;
+        for (int i = 0; i < ks; ++i) {
+          int yy = y + i - h; yy = yy < 0 ? -yy : yy; yy = yy >= S ? 2 * S - 2 - yy : yy;
+          float row = 0.f;
+          for (int j = 0; j < ks; ++j) {
+            int xx = x + j - h; xx = xx < 0 ? -xx : xx; xx = xx >= S ? 2 * S - 2 - xx : xx;
+            row = __fadd_rn(row, __fmul_rn(gk[j], aug_point(fr, Wr, y0, x0, S, yy, xx, c, mode_b, bright, contrast, alpha)));
+          }
+          acc = __fadd_rn(acc, __fmul_rn(gk[i], row));
+        }
+        v[c] = acc;
+      }
+    }
+    const float v0 = v[0] - m0, v1 = v[1] - m1, v2 = v[2] - m2;
+    if (layout == 0) {
+      const int64_t plane = (int64_t)T * S * S, o = (int64_t)b * 3 * plane + ((int64_t)t * S + y) * S + x;
+      out[o] = v0; out[o + plane] = v1; out[o + 2 * plane] = v2;
+    } else {
+      *(float4*)(out + e * 4) = make_float4(v0, v1, v2, 0.f);
+    }
+  }
+}
+extern "C" int md_clip_augment_preprocess(const uint8_t* frames, int32_t B, int32_t T, int32_t Hr, int32_t Wr, int32_t S,
+                                          const float* mean_bgr, int32_t layout, const int32_t* params, const float* gauss, float* out,
+                                          void* stream) {
+  if (!frames || !mean_bgr || !out || !params || !gauss) return MD_ERR_NULL;
+  if (B <= 0 || T <= 0 || Hr <= 0 || Wr <= 0 || S <= 0 || (S & 1) || S > Hr || S > Wr || (layout != 0 && layout != 1)) return MD_ERR_BAD_SHAPE;
+  const int64_t n = (int64_t)B * T * S * S;
+  int64_t blocks = (n + 255) / 256; if (blocks > 65536) blocks = 65536;
+  MD_KLAUNCH(k_clip_augment, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, frames, B, T, Hr, Wr, S, Hr / 2 - S / 2,
+             Wr / 2 - S / 2, mean_bgr[0], mean_bgr[1], mean_bgr[2], layout, params, gauss, out);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+
 // ---------------------------------------------------------------- class-balanced re-sampling (ImbalancedDatasetSampler)
 // torch.multinomial(weights, n, replacement=True) on the CPU (the reference's sampler, src/utils/sampler.py:29-32) is: cumulative
 // distribution of the normalised weights, then for each draw a uniform double u and the LEFTMOST category whose cumulative

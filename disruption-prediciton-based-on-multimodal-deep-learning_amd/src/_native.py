@@ -120,6 +120,7 @@ SIGNATURES = {
     "md_lstm_rec_fwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P]),
     "md_lstm_rec_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P]),
     "md_clip_preprocess": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, C.POINTER(C.c_float), _I32, _P, _P]),
+    "md_clip_augment_preprocess": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, C.POINTER(C.c_float), _I32, _P, _P, _P, _P]),
     "md_multinomial_shard_count": (C.c_int64, [C.c_int64, _I32, _I32]),
     "md_multinomial_shard": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _I32, _I32, _P, _P, _P]),
     "md_outer_fwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P]),

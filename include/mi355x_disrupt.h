@@ -301,6 +301,13 @@ int md_gelu(const float* x, const float* dy, int32_t kind, int64_t n, float* out
  * layout 1: out [B][T][S][S][4] with channel 3 = 0 (the kernels' channels-last layout).  Exact: uint8 -> fp32 minus the mean. */
 int md_clip_preprocess(const uint8_t* frames, int32_t B, int32_t T, int32_t Hr, int32_t Wr, int32_t S, const float* mean_bgr,
                        int32_t layout, float* out, void* stream);
+/* The same with the six augmentations of :129-135, 152-227 between crop and mean subtraction.  params [B][10] int32 (device):
+ * brightness mode (0 none / 1 add + clip to [10,255] / 2 add + horizontal flip), brightness amount, contrast on, contrast alpha,
+ * blur on, blur kernel size, row_lo, row_hi, col_lo, col_hi (pixels outside [lo,hi) become 0 before the mean subtraction: the
+ * reference's vertical_shift / horizontal_shift mask edges, they do not shift); gauss: the kernel-size Gaussian weights (device).
+ * The host draws the decisions (src/utils/clip_preprocess.py::draw_augmentation: the reference's random-number calls in order). */
+int md_clip_augment_preprocess(const uint8_t* frames, int32_t B, int32_t T, int32_t Hr, int32_t Wr, int32_t S, const float* mean_bgr,
+                               int32_t layout, const int32_t* params, const float* gauss, float* out, void* stream);
 
 /* Class-balanced re-sampling as a device-side, rank-sharded index stream (ImbalancedDatasetSampler, src/utils/sampler.py:5-35:
  * torch.multinomial with replacement over 1 / class-count weights).  cum_dist: the normalised cumulative distribution in

@@ -33,7 +33,7 @@ class _Quiet:
 
 
 FRAMES = {}
-for name, attrs in (("cv2", dict(imread=lambda p: FRAMES[p])),
+for name, attrs in (("cv2", dict(imread=lambda p: FRAMES[p], flip=lambda a, flipCode=1: np.ascontiguousarray(a[:, ::-1]))),
                     ("glob2", dict(glob=lambda pat: [k for k in FRAMES if os.path.dirname(k) == os.path.dirname(pat)])),
                     ("torchvision", {}), ("torchvision.transforms", {})):
     m = types.ModuleType(name)
@@ -180,6 +180,21 @@ def main():
         clip, lab = dv[i]
         rec["dsv/clip%d" % i] = MG.subsample(clip, 96)
     print("DatasetForVideo", len(dv), dv.labels)
+    # ---- augmentations (src/dataset.py:129-135, 152-227): everything that does not need OpenCV (contrast / blur probability 0) ------
+    import random as pyrandom
+    AUG = {"bright_val": 30, "bright_p": 0.7, "contrast_min": 1, "contrast_max": 1.15, "contrast_p": 0.0, "blur_k": 5, "blur_p": 0.0,
+           "flip_p": 0.5, "vertical_ratio": 0.2, "vertical_p": 0.7, "horizontal_ratio": 0.2, "horizontal_p": 0.7}
+    da = DatasetForVideo(["/shots/%d" % SHOT], df, augmentation=True, augmentation_args=dict(AUG), crop_size=128, seq_len=CLIP, dist=DIST)
+    pyrandom.seed(1234); np.random.seed(4321)
+    clips = []
+    for rep in range(8):
+        clips.append(da[rep % len(da)][0].numpy())
+    rec["aug/args"] = np.array([AUG[k] for k in sorted(AUG)], dtype=np.float64)
+    rec["aug/seeds"] = np.array([1234, 4321])
+    for i, c in enumerate(clips):
+        rec["aug/clip%d" % i] = MG.subsample(torch.from_numpy(c), 4096)
+        rec["aug/sum%d" % i] = np.float64(c.astype(np.float64).sum())
+    print("augmentation: 8 clips recorded")
     # ---- generate_prob_curve_from_multi (utility.py:1068-1178): MultiModalDataset index matching + curve assembly --------------
     from src.models.MultiModal import MultiModalModel     # reference
     SHOT2, SRT2, END2 = 21311, 20, 200

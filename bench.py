@@ -127,8 +127,12 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
-    if world > 1:
+    # MD_BENCH_FORCE_DP=1: run the data-parallel code path (RCCL process group, stage-wise all-reduce, sync-free skip) with
+    # whatever WORLD_SIZE is -- with one rank it is how the RCCL path can be exercised on a one-GPU box
+    dp = world > 1 or os.environ.get("MD_BENCH_FORCE_DP") == "1"
+    if dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from src.models.R2Plus1D import R2Plus1DClassifier
@@ -139,7 +143,7 @@ def main():
     model = R2Plus1DClassifier(input_size=(3, T, S, S), num_classes=2, layer_sizes=LAYERS, alpha=ALPHA).to(device)
     model.train()
     reducer = None
-    if world > 1:
+    if dp:
         broadcast_module_state(model, 0)
         reducer = GradAllReducer(model)
     loss_fn = FocalLoss(weight=torch.ones(2), gamma=2.0)
@@ -189,7 +193,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -222,7 +226,7 @@ def main():
     if float(finite.item()) != 1.0:
         raise SystemExit("non-finite loss inside the timed region")
     tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-    if world > 1:
+    if dp:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
@@ -264,7 +268,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "R2Plus1D layer_sizes=[1,2,2,1] alpha=0.01, per-GPU clips (8,3,21,128,128) fp32, "
                                    "forward+FocalLoss(gamma=2)+backward+clip_grad_norm(1.0)+AdamW(2e-4), BN in train mode",
-                       "per_gpu_batch": B_PER_GPU, "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}"},
+                       "per_gpu_batch": B_PER_GPU, "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}" + (" (data-parallel code path forced)" if dp and world == 1 else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": dom, "launches": int(d_n), "avg_launch_ms": round(d_ms / max(1, d_n), 5),
@@ -285,7 +289,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dp:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -34,3 +34,22 @@ def test_trunk_stage_hook_allreduce_two_ranks():
         assert r["steps"] == [1]                      # the skipped step does not advance Adam's step count
     for a, b in zip(r0["after"], r1["after"]):
         assert torch.equal(a, b)                      # replicas identical after the applied step
+
+
+@pytest.mark.gpu
+def test_bench_data_parallel_path_runs_on_rccl_with_one_rank():
+    """The N>1 leg of bench.py (RCCL process group, broadcast, GradAllReducer with its side-stream ordering, dp_train_step with the
+    finite flag in the last bucket and the device-side skip) on the real `nccl` backend -- with ONE rank, which is all a one-GPU box
+    can host: every collective is a real RCCL call on this GPU.  The step time must be that of the single-process step (the
+    all-reduces are no-ops in data volume) and the JSON line well formed."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MD_BENCH_FORCE_DP="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29519",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "3", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and "forced" in d["config"]["parallelism"] and d["value"] > 0
+    assert d["ms_per_step"] < 12.0, d["ms_per_step"]

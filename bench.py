@@ -130,7 +130,13 @@ def main():
     # MD_BENCH_FORCE_DP=1: run the data-parallel code path (RCCL process group, stage-wise all-reduce, sync-free skip) with
     # whatever WORLD_SIZE is -- with one rank it is how the RCCL path can be exercised on a one-GPU box
     dp = world > 1 or os.environ.get("MD_BENCH_FORCE_DP") == "1"
+    saved_stdout = None
     if dp:
+        # RCCL prints a five-line version banner on STDOUT when a communicator is created (lazily, at the first collective of a
+        # stream): the contract is ONE JSON line on stdout, so file descriptor 1 points at stderr until rank 0 prints its line
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -288,7 +294,12 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+        if saved_stdout is not None:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
+        if saved_stdout is not None:
+            os.dup2(2, 1)                    # whatever the teardown prints does not follow the JSON line
     if dp:
         dist.barrier()
         dist.destroy_process_group()

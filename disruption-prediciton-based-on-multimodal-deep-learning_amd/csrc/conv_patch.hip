@@ -1493,7 +1493,11 @@ const WgradPlan* wgrad_lookup(const MdConvDesc* d, int xpitch, int xc0, int dw_c
     // eight-wave form of the prefetching kernel where only one 4-wave workgroup would fit a CU
     static const int w8_env = getenv("MD_WGRAD_W8") ? atoi(getenv("MD_WGRAD_W8")) : 1;
     const bool w8 = w8_env && occ == 1 && wgrad_use_pf(g) && g.nrep >= 2;
-    int want = md_cdiv(fill * occ, g.nkg * g.nng);
+    // the stem's weight gradient (pixel-pair form) is the LAST kernel of the backward pass: nothing runs beside it any more, so it
+    // is sized for the whole chip
+    static const int tail_full = !(getenv("MD_WGRAD_TAIL_FULL") && atoi(getenv("MD_WGRAD_TAIL_FULL")) == 0);
+    const int fill_eff = (g.pack2 && tail_full) ? 256 : fill;
+    int want = md_cdiv(fill_eff * occ, g.nkg * g.nng);
     if (want > g.nboxes) want = g.nboxes;
     if (want < 1) want = 1;
     g.boxes_per_wg = md_cdiv(g.nboxes, want);

@@ -49,7 +49,8 @@ def test_bench_data_parallel_path_runs_on_rccl_with_one_rank():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "3", "--no-cpu-baseline"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    d = json.loads(line)
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines[:6]          # ONE JSON line on stdout (RCCL's version banner must not be there)
+    d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and "forced" in d["config"]["parallelism"] and d["value"] > 0
     assert d["ms_per_step"] < 12.0, d["ms_per_step"]

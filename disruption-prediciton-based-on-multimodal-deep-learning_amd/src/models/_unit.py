@@ -17,13 +17,22 @@ from .. import ops
 
 class ConvBnLeakyFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, rmean, rvar, stride, padding, slope, training, eps, momentum):
+    def forward(ctx, x, w, gamma, beta, rmean, rvar, stride, padding, slope, training, eps, momentum, cl_channels=0):
+        # cl_channels > 0: x is already the kernels' channels-last tensor (B,T,H,W,Cp) with that many channels, and the result
+        # is handed on in the same layout (CLAct, below): no layout conversion at either end
         x = x.contiguous()                   # (strided views such as x[:, :, ::tau] are packed here: memory plumbing)
         ops.require_cuda(x, w, gamma, beta)
-        B, Cin, T, H, W = x.shape
+        if cl_channels:
+            B, T, H, W, _ = x.shape
+            Cin = int(cl_channels)
+            xcl = x.float()
+        else:
+            B, Cin, T, H, W = x.shape
+            xcl = None
         Cout = w.shape[0]
         d = ops.make_desc(B, T, H, W, Cin, Cout, tuple(w.shape[2:]), tuple(stride), tuple(padding))
-        xcl = ops.to_channels_last(x.contiguous().float())
+        if xcl is None:
+            xcl = ops.to_channels_last(x.contiguous().float())
         wf, wd = ops.pack_weights(d, w.contiguous(), want_dgrad=training)
         y, part = ops.conv_fwd(d, ops.view(xcl), wf, x.device, want_stats=training)
         rows = y.numel() // y.shape[-1]
@@ -35,12 +44,13 @@ class ConvBnLeakyFunction(torch.autograd.Function):
                                               ops._p(st[0]), ops._p(st[1]), ops._p(st[2]), ops._p(st[3]), ops._stream()),
                     "md_bn_eval_params")
         a = ops.bn_act(ops.view(y, st[2], st[3], slope), y, Cout)
-        out = ops.from_channels_last(a, Cout)
+        out = a if cl_channels else ops.from_channels_last(a, Cout)
         if training:
             ctx.d = d
             ctx.slope = slope
             ctx.save_for_backward(xcl, y, st, wd)
         ctx.training = training
+        ctx.cl = bool(cl_channels)
         return out
 
     @staticmethod
@@ -49,18 +59,81 @@ class ConvBnLeakyFunction(torch.autograd.Function):
             raise RuntimeError("mi355x hot path: backward through an eval-mode BatchNorm unit is not supported")
         xcl, y, st, wd = ctx.saved_tensors
         d = ctx.d
-        dA = ops.to_channels_last(dout.contiguous().float())
+        dA = dout.contiguous().float() if ctx.cl else ops.to_channels_last(dout.contiguous().float())
         d_raw, _, dgamma, dbeta = ops.bn_backward(dA, ops.view(y, st[2], st[3], ctx.slope), st, d.Cout)
         dw = ops.conv_wgrad(d, ops.view(xcl), d_raw)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = ops.from_channels_last(ops.conv_dgrad(d, d_raw, wd), d.Cin)
-        return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None, None
+            dx = ops.conv_dgrad(d, d_raw, wd)
+            if not ctx.cl:
+                dx = ops.from_channels_last(dx, d.Cin)
+        return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+
+
+class CLAct:
+    """An activation kept in the kernels' channels-last layout between units: ``t`` (B,T,H,W,Cp) fp32 with the padding channels
+    exactly zero, ``C`` real channels.  The native ResNet3D stages hand these from unit to unit (conv+BN units, Swish, the
+    residual close are layout-agnostic or channels-last native), so the (B,C,T,H,W) <-> channels-last conversion kernels run
+    at the stage boundaries that need the reference layout only (stem pooling, squeeze-excitation, the final pool)."""
+    __slots__ = ("t", "C")
+
+    def __init__(self, t: torch.Tensor, C: int):
+        self.t, self.C = t, int(C)
+
+    @property
+    def shape(self):                         # the logical (B,C,T,H,W) shape
+        B, T, H, W, _ = self.t.shape
+        return (B, self.C, T, H, W)
+
+
+class _ToCLFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.C = x.shape[1]
+        return ops.to_channels_last(x.contiguous().float())
+
+    @staticmethod
+    def backward(ctx, dout):
+        return ops.from_channels_last(dout.contiguous().float(), ctx.C)
+
+
+class _FromCLFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xcl, C):
+        return ops.from_channels_last(xcl.contiguous().float(), int(C))
+
+    @staticmethod
+    def backward(ctx, dout):
+        return ops.to_channels_last(dout.contiguous().float()), None
+
+
+def to_cl_act(x: torch.Tensor) -> CLAct:
+    return CLAct(_ToCLFunction.apply(x), x.shape[1])
+
+
+def from_cl_act(a: CLAct) -> torch.Tensor:
+    return _FromCLFunction.apply(a.t, a.C)
+
+
+def cat_cl(a: CLAct, b: CLAct) -> CLAct:
+    """torch.cat([a, b], dim=1) of the logical tensors, in the channels-last layout (padding re-established at the end)."""
+    Cc = a.C + b.C
+    t = torch.cat((a.t[..., :a.C], b.t[..., :b.C]), dim=-1)
+    pad = ops.cpad(Cc) - Cc
+    if pad:
+        t = torch.nn.functional.pad(t, (0, pad))
+    return CLAct(t.contiguous(), Cc)
 
 
 def conv_bn_leaky(x, conv: torch.nn.Conv3d, bn: torch.nn.BatchNorm3d, slope: float, training: bool):
     if conv.bias is not None:
         raise NotImplementedError("mi355x hot path: Conv3dBlock with bias=True is not used by the reference")
+    if isinstance(x, CLAct):
+        out = ConvBnLeakyFunction.apply(x.t, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.stride,
+                                        conv.padding, float(slope), bool(training), float(bn.eps), float(bn.momentum), x.C)
+        if training:
+            bn.num_batches_tracked += 1
+        return CLAct(out, conv.weight.shape[0])
     out = ConvBnLeakyFunction.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.stride,
                                     conv.padding, float(slope), bool(training), float(bn.eps), float(bn.momentum))
     if training:
@@ -111,32 +184,44 @@ class ConvFunction(torch.autograd.Function):
     """Plain Conv3d (no bias, no normalisation): the SlowFast laterals (reference slowfast.py:58-65)."""
 
     @staticmethod
-    def forward(ctx, x, w, stride, padding):
+    def forward(ctx, x, w, stride, padding, cl_channels=0):
         x = x.contiguous()
         ops.require_cuda(x, w)
-        B, Cin, T, H, W = x.shape
+        if cl_channels:
+            B, T, H, W, _ = x.shape
+            Cin = int(cl_channels)
+            xcl = x.float()
+        else:
+            B, Cin, T, H, W = x.shape
+            xcl = ops.to_channels_last(x.contiguous().float())
         Cout = w.shape[0]
         d = ops.make_desc(B, T, H, W, Cin, Cout, tuple(w.shape[2:]), tuple(stride), tuple(padding))
-        xcl = ops.to_channels_last(x.contiguous().float())
         wf, wd = ops.pack_weights(d, w.contiguous(), want_dgrad=True)
         y, _ = ops.conv_fwd(d, ops.view(xcl), wf, x.device, want_stats=False)
         ctx.d = d
+        ctx.cl = bool(cl_channels)
         ctx.save_for_backward(xcl, wd)
-        return ops.from_channels_last(y, Cout)
+        return y if cl_channels else ops.from_channels_last(y, Cout)
 
     @staticmethod
     def backward(ctx, dout):
         xcl, wd = ctx.saved_tensors
         d = ctx.d
-        dy = ops.to_channels_last(dout.contiguous().float())
+        dy = dout.contiguous().float() if ctx.cl else ops.to_channels_last(dout.contiguous().float())
         dw = ops.conv_wgrad(d, ops.view(xcl), dy)
-        dx = ops.from_channels_last(ops.conv_dgrad(d, dy, wd), d.Cin) if ctx.needs_input_grad[0] else None
-        return dx, dw, None, None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv_dgrad(d, dy, wd)
+            if not ctx.cl:
+                dx = ops.from_channels_last(dx, d.Cin)
+        return dx, dw, None, None, None
 
 
 def conv_plain(x, conv: torch.nn.Conv3d):
     if conv.bias is not None:
         raise NotImplementedError("mi355x hot path: plain convolution with bias is not used by the reference")
+    if isinstance(x, CLAct):
+        return CLAct(ConvFunction.apply(x.t, conv.weight, conv.stride, conv.padding, x.C), conv.weight.shape[0])
     return ConvFunction.apply(x, conv.weight, conv.stride, conv.padding)
 
 

@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from .. import _native as N
 from .. import ops
-from ._unit import _AbsorbedBias, conv_bn_leaky
+from ._unit import CLAct, _AbsorbedBias, conv_bn_leaky, from_cl_act, to_cl_act
 
 
 class SwishEfficient(torch.autograd.Function):
@@ -155,14 +155,24 @@ class Bottleneck3D(nn.Module):
         raise NotImplementedError("mi355x hot path: downsample must be Sequential(Conv3d(bias=False), BatchNorm3d)")
 
     def forward(self, x):
+        """x: a (B,C,T,H,W) tensor, or a CLAct (the channels-last activation the native stages pass between blocks: then every
+        unit, the Swish and the residual close work on that layout and a CLAct comes back; only the squeeze-excitation gate,
+        whose pooling kernel wants channel planes, converts there and back)."""
+        cl = isinstance(x, CLAct)
         out = conv_bn_leaky(x, self.conv1, self.bn1, 0.0, self.training)       # conv1 -> bn1 -> relu
         out = conv_bn_leaky(out, self.conv2, self.bn2, 0.0, self.training)     # conv2 -> bn2 -> relu
         if self.index % 2 == 0:
-            out = _SESwishFunction.apply(out, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+            a = from_cl_act(out) if cl else out
+            a = _SESwishFunction.apply(a, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+            out = to_cl_act(a) if cl else a
+        elif cl:
+            out = CLAct(SwishEfficient.apply(out.t), out.C)                    # elementwise, swish(0) = 0 keeps the padding
         else:
             out = SwishEfficient.apply(out)
         out = conv_bn_leaky(out, self.conv3, self.bn3, 1.0, self.training)     # conv3 -> bn3
         residual = x if self.downsample is None else self._downsample(x)
+        if cl:
+            return CLAct(_AddReluFunction.apply(out.t, residual.t), out.C)
         return _AddReluFunction.apply(out, residual)
 
 

@@ -14,7 +14,12 @@ import torch.nn as nn
 
 from .resnet import *          # noqa: F401,F403  (as the reference does, slowfast.py:5)
 from .resnet import Bottleneck3D, ResNet3D
-from ._unit import GlobalAvgPoolFunction, conv_plain, head_apply
+import os
+
+from ._unit import GlobalAvgPoolFunction, cat_cl, conv_plain, from_cl_act, head_apply, to_cl_act
+
+# the stages keep their activations in the kernels' channels-last layout (MD_SLOWFAST_CL=0: reference layout at every unit boundary)
+_CL = not (os.environ.get("MD_SLOWFAST_CL") == "0")
 
 
 _STAGES = ("layer1", "layer2", "layer3", "layer4")
@@ -31,6 +36,11 @@ class SlowNet(ResNet3D):
     def forward(self, x: Tuple[torch.Tensor, List[torch.Tensor]]):
         h, laterals = x
         h = self.stem(h)
+        if _CL:
+            h = to_cl_act(h)
+            for name, lat in zip(_STAGES, laterals):
+                h = getattr(self, name)(cat_cl(h, lat))
+            return GlobalAvgPoolFunction.apply(from_cl_act(h))
         for name, lat in zip(_STAGES, laterals):
             h = getattr(self, name)(torch.cat([h, lat], dim=1))
         return GlobalAvgPoolFunction.apply(h)
@@ -54,11 +64,14 @@ class FastNet(ResNet3D):
 
     def forward(self, x: torch.Tensor):
         h = self.stem(x)
+        if _CL:
+            h = to_cl_act(h)
         laterals = [conv_plain(h, self.l_maxpool)]
         for name, lat in zip(_STAGES[:3], _LATERALS[1:]):
             h = getattr(self, name)(h)
             laterals.append(conv_plain(h, getattr(self, lat)))
-        return GlobalAvgPoolFunction.apply(self.layer4(h)), laterals
+        h = self.layer4(h)
+        return GlobalAvgPoolFunction.apply(from_cl_act(h) if _CL else h), laterals
 
 
 def resnet50_f(block=Bottleneck3D, layers=[3, 4, 6, 3], **kwargs):

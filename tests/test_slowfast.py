@@ -79,3 +79,34 @@ def test_native_slowfast_matches_reference_fixture(golden_dir, exact):
     m.eval()
     with torch.no_grad():
         assert tuple(m(x).shape) == (B, 2) and tuple(m.encode(x).shape) == (B, 640)
+
+
+@pytest.mark.gpu
+def test_channels_last_resident_stages_are_bit_identical_to_the_reference_layout_path():
+    """SlowFast with the stage activations kept in the kernels' channels-last layout (CLAct: no (B,C,T,H,W) <-> channels-last
+    conversion between units) against the same model converting at every unit boundary: same kernels on the same bytes, so
+    logits and every parameter gradient must agree bit for bit."""
+    import src.models.slowfast as sfm
+    torch.manual_seed(3)
+    m = sfm.SlowFast(input_shape=(3, 8, 32, 32), layers=[1, 2, 1, 1], alpha=4, tau_fast=1, num_classes=2).cuda().train()
+    x = torch.randn(2, 3, 8, 32, 32, device="cuda")
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    res = {}
+    old = sfm._CL
+    try:
+        for flag in (True, False):
+            sfm._CL = flag
+            m.load_state_dict(sd)
+            for p in m.parameters():
+                p.grad = None
+            out = m(x)
+            out.square().sum().backward()
+            res[flag] = (out.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()},
+                         {k: v.clone() for k, v in m.state_dict().items() if "running" in k})
+    finally:
+        sfm._CL = old
+    assert torch.equal(res[True][0], res[False][0])
+    for k in res[True][1]:
+        assert torch.equal(res[True][1][k], res[False][1][k]), k
+    for k in res[True][2]:
+        assert torch.equal(res[True][2][k], res[False][2][k]), k

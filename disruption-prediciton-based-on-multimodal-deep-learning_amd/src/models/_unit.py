@@ -769,7 +769,11 @@ def head_apply(f, lin0: torch.nn.Linear, bn: torch.nn.BatchNorm1d, lin1: torch.n
     fit (MLSTM_FCN's 512 -> 256 head at batch 32, BASELINE configs[0]) the head is composed from the Linear+BatchNorm1d unit,
     md_elu and the MFMA Linear instead."""
     B, Hd = f.shape[0], lin0.out_features
-    if 2 * B * Hd * 4 <= 60000:
+    # wide heads (SlowFast: 640 -> 320): the fused kernels are ONE workgroup walking the whole weight matrix (350 us per pass at
+    # 640 x 320); above 64k weights the composed form (MFMA Linear kernels over all CUs) is the faster one.  MD_HEAD_FUSED_MAX overrides.
+    import os
+    fused_max = int(os.environ.get("MD_HEAD_FUSED_MAX", "65536"))
+    if 2 * B * Hd * 4 <= 60000 and lin0.in_features * Hd <= fused_max:
         out = HeadFunction.apply(f, lin0.weight, lin0.bias, bn.weight, bn.bias, lin1.weight, lin1.bias, bn.running_mean, bn.running_var,
                                  float(alpha), float(bn.eps), float(bn.momentum), bool(training))
         if training:

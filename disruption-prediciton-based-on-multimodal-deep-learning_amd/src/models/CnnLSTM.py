@@ -18,6 +18,7 @@ import torch.nn as nn
 from .. import _native as N
 from .. import ops
 from .NoiseLayer import NoiseLayer
+from ._unit import bump_batches_tracked
 from ._unit import (ConvBnLeakyFunction, ConvFunction, HeadFunction, head_apply, lstm_forward, _AbsorbedBias, _ChannelBias,
                     _SeqSum)
 
@@ -80,7 +81,7 @@ class CnnLSTM(nn.Module):
                                       float(bn.eps), float(bn.momentum))
         if self.training:
             bn.running_mean.add_(b * bn.momentum)
-            bn.num_batches_tracked += 1
+            bump_batches_tracked(bn)
             z = _AbsorbedBias.apply(z, c2.bias)
         return z[:, :, :, 0, 0]
 

@@ -15,6 +15,35 @@ from .. import _native as N
 from .. import ops
 
 
+# BatchNorm's num_batches_tracked is a device tensor: ``+= 1`` per unit is one tiny launch per BatchNorm per step (50 in SlowFast).
+# Inside ``deferred_bn_counters()`` -- the models' forward() -- the increments are collected and applied by ONE _foreach_add_.
+_counter_depth = 0
+_counter_pending = []
+
+
+class deferred_bn_counters:
+    def __enter__(self):
+        global _counter_depth
+        _counter_depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _counter_depth
+        _counter_depth -= 1
+        if _counter_depth == 0 and _counter_pending:
+            pend = list(_counter_pending)
+            _counter_pending.clear()
+            torch._foreach_add_(pend, 1)
+        return False
+
+
+def bump_batches_tracked(bn) -> None:
+    if _counter_depth > 0:
+        _counter_pending.append(bn.num_batches_tracked)
+    else:
+        bn.num_batches_tracked += 1
+
+
 class ConvBnLeakyFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, gamma, beta, rmean, rvar, stride, padding, slope, training, eps, momentum, cl_channels=0):
@@ -132,12 +161,12 @@ def conv_bn_leaky(x, conv: torch.nn.Conv3d, bn: torch.nn.BatchNorm3d, slope: flo
         out = ConvBnLeakyFunction.apply(x.t, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.stride,
                                         conv.padding, float(slope), bool(training), float(bn.eps), float(bn.momentum), x.C)
         if training:
-            bn.num_batches_tracked += 1
+            bump_batches_tracked(bn)
         return CLAct(out, conv.weight.shape[0])
     out = ConvBnLeakyFunction.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.stride,
                                     conv.padding, float(slope), bool(training), float(bn.eps), float(bn.momentum))
     if training:
-        bn.num_batches_tracked += 1
+        bump_batches_tracked(bn)
     return out
 
 
@@ -529,7 +558,7 @@ def _unit_with_bias(x5, w5, bias, bn, stride, padding, slope: float, training: b
         if b is not None:
             bn.running_mean.add_(b * bn.momentum)
             z = _AbsorbedBias.apply(z, bias)
-        bn.num_batches_tracked += 1
+        bump_batches_tracked(bn)
     return z
 
 
@@ -777,7 +806,7 @@ def head_apply(f, lin0: torch.nn.Linear, bn: torch.nn.BatchNorm1d, lin1: torch.n
         out = HeadFunction.apply(f, lin0.weight, lin0.bias, bn.weight, bn.bias, lin1.weight, lin1.bias, bn.running_mean, bn.running_var,
                                  float(alpha), float(bn.eps), float(bn.momentum), bool(training))
         if training:
-            bn.num_batches_tracked += 1
+            bump_batches_tracked(bn)
         return out
     if alpha < 0:
         h = linear_bn_leaky(f, lin0, bn, -float(alpha), bool(training))

@@ -62,7 +62,9 @@ class FusionGB(nn.Module):
         pass
 
     def forward(self, x_vis: torch.Tensor, x_ts: torch.Tensor):
-        return self.forward_stream(x_vis, x_ts)
+        from ._unit import deferred_bn_counters
+        with deferred_bn_counters():                   # every BatchNorm step counter of both encoders in one launch
+            return self.forward_stream(x_vis, x_ts)
 
     def forward_stream(self, x_vis: torch.Tensor, x_ts: torch.Tensor):
         if self.use_stream == "video":

@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from .. import _native as N
 from .. import ops
-from ._unit import CLAct, _AbsorbedBias, conv_bn_leaky, from_cl_act, to_cl_act
+from ._unit import CLAct, _AbsorbedBias, bump_batches_tracked, conv_bn_leaky, from_cl_act, to_cl_act
 
 
 class SwishEfficient(torch.autograd.Function):
@@ -189,7 +189,7 @@ def _conv_bias_bn_relu(x, conv: nn.Conv3d, bn: nn.BatchNorm3d, training: bool):
                                     bool(training), float(bn.eps), float(bn.momentum))
     if training:
         bn.running_mean.add_(b * bn.momentum)                                  # the batch mean of (y + b) is mean(y) + b
-        bn.num_batches_tracked += 1
+        bump_batches_tracked(bn)
         out = _AbsorbedBias.apply(out, conv.bias)
     return out
 

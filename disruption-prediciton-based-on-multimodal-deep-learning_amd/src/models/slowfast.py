@@ -16,7 +16,7 @@ from .resnet import *          # noqa: F401,F403  (as the reference does, slowfa
 from .resnet import Bottleneck3D, ResNet3D
 import os
 
-from ._unit import GlobalAvgPoolFunction, cat_cl, conv_plain, from_cl_act, head_apply, to_cl_act
+from ._unit import GlobalAvgPoolFunction, cat_cl, conv_plain, deferred_bn_counters, from_cl_act, head_apply, to_cl_act
 
 # the stages keep their activations in the kernels' channels-last layout (MD_SLOWFAST_CL=0: reference layout at every unit boundary)
 _CL = not (os.environ.get("MD_SLOWFAST_CL") == "0")
@@ -99,10 +99,11 @@ class SlowFastEncoder(nn.Module):
         return x[:, :, ::tau_slow, :, :], x[:, :, ::tau_fast, :, :]
 
     def forward(self, x: torch.Tensor):
-        x_slow, x_fast = self.split_slow_fast(x)
-        x_fast, laterals = self.fastnet(x_fast)
-        x_slow = self.slownet((x_slow, laterals))
-        return torch.cat([x_slow, x_fast], dim=1)
+        with deferred_bn_counters():                   # one launch for all BatchNorm step counters instead of one per unit
+            x_slow, x_fast = self.split_slow_fast(x)
+            x_fast, laterals = self.fastnet(x_fast)
+            x_slow = self.slownet((x_slow, laterals))
+            return torch.cat([x_slow, x_fast], dim=1)
 
     def show_CAM(self):
         pass

@@ -12,6 +12,7 @@
 // leaves the product unchanged.  LDS row pitch 40 floats makes those b128 reads bank-conflict free.
 #include <cstdlib>
 #include "common.h"
+#include <vector>
 #include "patch_common.h"
 
 #define BM 128          // destination rows per workgroup
@@ -451,6 +452,28 @@ extern "C" int md_conv_pack_weights(const MdConvDesc* d, const float* w, float* 
   MD_KLAUNCH(k_pack_weights, dim3(md_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w, d->Cout, d->Cin,
                      taps, wf, gf.Cpi, gf.Kp, gf.N16, wd, gd.Cpi, gd.Kp, gd.N16);
   MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+// Many units at once (the composable models pack ~120 operands per training step, one tiny launch each): the patch-format
+// operands of all of them go through the batched kernel (<= 64 per launch), the rest one by one.  wf[i] / wd[i] may be NULL.
+extern "C" int md_conv_pack_weights_batch(int32_t n, const MdConvDesc* descs, const float* const* w, float* const* wf, float* const* wd,
+                                          void* stream) {
+  if (n < 0 || (n > 0 && (!descs || !w || !wf || !wd))) return MD_ERR_NULL;
+  for (int i = 0; i < n; ++i) { int rc = check_desc(&descs[i]); if (rc != MD_OK) return rc; if (!w[i]) return MD_ERR_NULL; }
+  std::vector<const MdConvDesc*> dp(2 * n); std::vector<int> dg(2 * n);
+  std::vector<const float*> wsrc(2 * n); std::vector<float*> outs(2 * n); std::vector<unsigned char> handled(2 * n);
+  for (int i = 0; i < n; ++i) {
+    dp[2 * i] = &descs[i]; dg[2 * i] = 0; wsrc[2 * i] = w[i]; outs[2 * i] = wf[i];
+    dp[2 * i + 1] = &descs[i]; dg[2 * i + 1] = 1; wsrc[2 * i + 1] = w[i]; outs[2 * i + 1] = wd[i];
+  }
+  int rc = patch_pack_batch(2 * n, dp.data(), dg.data(), wsrc.data(), outs.data(), handled.data(), (hipStream_t)stream);
+  if (rc) return rc;
+  for (int i = 0; i < n; ++i) {
+    float* f = handled[2 * i] ? nullptr : wf[i];
+    float* d = handled[2 * i + 1] ? nullptr : wd[i];
+    if (f || d) { rc = md_conv_pack_weights(&descs[i], w[i], f, d, stream); if (rc) return rc; }
+  }
   return MD_OK;
 }
 

@@ -42,6 +42,7 @@ SIGNATURES = {
     "md_conv_wpack_fwd_floats": (_SZ, [_DESC]),
     "md_conv_wpack_dgrad_floats": (_SZ, [_DESC]),
     "md_conv_pack_weights": (C.c_int, [_DESC, _P, _P, _P, _P]),
+    "md_conv_pack_weights_batch": (C.c_int, [_I32, _P, _P, _P, _P, _P]),
     "md_conv_fwd_stat_blocks": (_I32, [_DESC]),
     "md_conv_fwd": (C.c_int, [_DESC, _VIEW, _P, _P, _P, _P]),
     "md_conv_dgrad": (C.c_int, [_DESC, _P, _P, _P, C.c_int, _P]),

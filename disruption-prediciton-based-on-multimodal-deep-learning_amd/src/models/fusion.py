@@ -62,8 +62,9 @@ class FusionGB(nn.Module):
         pass
 
     def forward(self, x_vis: torch.Tensor, x_ts: torch.Tensor):
+        from .. import ops
         from ._unit import deferred_bn_counters
-        with deferred_bn_counters():                   # every BatchNorm step counter of both encoders in one launch
+        with deferred_bn_counters(), ops.prepacked(self):   # BatchNorm step counters and weight packs of both encoders, batched
             return self.forward_stream(x_vis, x_ts)
 
     def forward_stream(self, x_vis: torch.Tensor, x_ts: torch.Tensor):

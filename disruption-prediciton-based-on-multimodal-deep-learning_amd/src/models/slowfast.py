@@ -99,7 +99,8 @@ class SlowFastEncoder(nn.Module):
         return x[:, :, ::tau_slow, :, :], x[:, :, ::tau_fast, :, :]
 
     def forward(self, x: torch.Tensor):
-        with deferred_bn_counters():                   # one launch for all BatchNorm step counters instead of one per unit
+        from .. import ops
+        with deferred_bn_counters(), ops.prepacked(self):   # one launch for all BatchNorm step counters / (almost) all weight packs
             x_slow, x_fast = self.split_slow_fast(x)
             x_fast, laterals = self.fastnet(x_fast)
             x_slow = self.slownet((x_slow, laterals))

@@ -85,8 +85,65 @@ def from_channels_last(x: torch.Tensor, channels: int) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------------------- conv
+# Batched packing for the composable models: pack_weights() remembers (descriptor, want_dgrad) per weight tensor; inside
+# ``prepacked(module)`` -- the models' forward() -- the operands of every remembered weight are packed up front by ONE batched
+# call (md_conv_pack_weights_batch: ~120 tiny launches per SlowFast step become 3) and pack_weights() hands them out.
+_pack_memo = {}        # id(weight) -> (weight (kept alive), descriptor fields, want_dgrad)
+_pack_ready = None     # inside prepacked(): id(weight) -> (descriptor fields, wf, wd)
+
+
+def _desc_key(d: N.MdConvDesc):
+    return tuple(getattr(d, f) for f, _ in d._fields_)
+
+
+class prepacked:
+    def __init__(self, module: torch.nn.Module):
+        ids = getattr(module, "_md_param_ids", None)
+        if ids is None:
+            ids = frozenset(id(p) for p in module.parameters())
+            module.__dict__["_md_param_ids"] = ids
+        self.ids = ids
+
+    def __enter__(self):
+        global _pack_ready
+        self.outer = _pack_ready
+        if self.outer is not None or not _pack_memo:
+            return self
+        items = [(wid, w, key, wd) for wid, (w, key, wd) in _pack_memo.items() if wid in self.ids and w.is_cuda]
+        if not items:
+            return self
+        L = N.lib()
+        n = len(items)
+        descs = (N.MdConvDesc * n)()
+        wp = (C.c_void_p * n)(); fp = (C.c_void_p * n)(); dp = (C.c_void_p * n)()
+        ready = {}
+        for i, (wid, w, key, want_d) in enumerate(items):
+            for (f, _), v in zip(N.MdConvDesc._fields_, key):
+                setattr(descs[i], f, v)
+            wc = w.detach().contiguous()
+            wf = torch.empty(L.md_conv_wpack_fwd_floats(C.byref(descs[i])), device=w.device, dtype=torch.float32)
+            wd = torch.empty(L.md_conv_wpack_dgrad_floats(C.byref(descs[i])), device=w.device, dtype=torch.float32) if want_d else None
+            wp[i] = wc.data_ptr(); fp[i] = wf.data_ptr(); dp[i] = wd.data_ptr() if wd is not None else None
+            ready[wid] = (key, wf, wd, wc)
+        N.check(L.md_conv_pack_weights_batch(n, descs, wp, fp, dp, _stream()), "md_conv_pack_weights_batch")
+        _pack_ready = ready
+        return self
+
+    def __exit__(self, *exc):
+        global _pack_ready
+        _pack_ready = self.outer
+        return False
+
+
 def pack_weights(d: N.MdConvDesc, w: torch.Tensor, want_dgrad: bool = True):
     require_cuda(w); f32(w)
+    key = _desc_key(d)
+    if _pack_ready is not None:
+        hit = _pack_ready.get(id(w))
+        if hit is not None and hit[0] == key and (hit[2] is not None or not want_dgrad):
+            return hit[1], (hit[2] if want_dgrad else None)
+    if isinstance(w, torch.nn.Parameter):                 # (views and temporaries have no stable identity)
+        _pack_memo[id(w)] = (w, key, bool(want_dgrad))
     L = N.lib()
     wf = torch.empty(L.md_conv_wpack_fwd_floats(C.byref(d)), device=w.device, dtype=torch.float32)
     wd = torch.empty(L.md_conv_wpack_dgrad_floats(C.byref(d)), device=w.device, dtype=torch.float32) if want_dgrad else None

@@ -78,6 +78,9 @@ size_t md_conv_wpack_fwd_floats(const MdConvDesc* d);
 size_t md_conv_wpack_dgrad_floats(const MdConvDesc* d);
 /* Pack the reference-layout weight (Cout,Cin,kt,kh,kw) into either operand (tiny kernel). */
 int md_conv_pack_weights(const MdConvDesc* d, const float* w, float* wpack_fwd, float* wpack_dgrad, void* stream);
+/* The same for n units in as few launches as possible (descs: array of n descriptors; wpack_fwd[i] / wpack_dgrad[i] may be NULL). */
+int md_conv_pack_weights_batch(int32_t n, const MdConvDesc* descs, const float* const* w, float* const* wpack_fwd,
+                               float* const* wpack_dgrad, void* stream);
 
 /* Number of row-blocks the forward kernel uses = rows of the BatchNorm partial-statistics buffer. */
 int32_t md_conv_fwd_stat_blocks(const MdConvDesc* d);

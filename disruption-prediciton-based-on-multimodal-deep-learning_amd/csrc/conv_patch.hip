@@ -803,7 +803,8 @@ static int patch_launch_one(const PatchPlan* p, const PGeom& g, size_t lds, cons
 bool patch_can_fuse(const PatchPlan* p) {
   if (!p->dgrad) return false;
   // instantiated without register spills: up to 3 channel tiles (and then at most 4 staged items per thread with 3)
-  auto ok = [](const PersVariant& pv) { return pv.on && pv.pg.g.N16 <= 48 && !(pv.pg.g.N16 == 48 && pv.pg.nit > 4); };
+  static const int maxn = getenv("MD_FUSE_MAXN16") ? atoi(getenv("MD_FUSE_MAXN16")) : 48;      // experiment: larger tile counts spill
+  auto ok = [](const PersVariant& pv) { return pv.on && pv.pg.g.N16 <= maxn && !(pv.pg.g.N16 == 48 && pv.pg.nit > 4) && !(pv.pg.g.N16 > 48 && pv.pg.nit > 4); };
   if (!p->ncls) return ok(p->pers);
   for (int c = 0; c < p->ncls; ++c) if (!ok(p->cls[c].pers)) return false;
   return true;

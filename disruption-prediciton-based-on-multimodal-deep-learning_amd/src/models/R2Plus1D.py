@@ -185,6 +185,7 @@ class R2Plus1DNet(nn.Module):
         rms = [u.bn.running_mean for u in units]
         rvs = [u.bn.running_var for u in units]
         # a backward can follow only if grad mode is on and something upstream of the features requires a gradient
+        ops.check_fp16_range(x, "the clip")
         need_bwd = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in ws + gs + bs))
         feat = TrunkFunction.apply(plan, x, rms, rvs, self.training, need_bwd, self.grad_segment_hook, *ws, *gs, *bs)
         if self.training:

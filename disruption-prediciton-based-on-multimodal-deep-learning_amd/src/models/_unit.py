@@ -51,6 +51,7 @@ class ConvBnLeakyFunction(torch.autograd.Function):
         # is handed on in the same layout (CLAct, below): no layout conversion at either end
         x = x.contiguous()                   # (strided views such as x[:, :, ::tau] are packed here: memory plumbing)
         ops.require_cuda(x, w, gamma, beta)
+        ops.check_fp16_range(x, "a convolution's input")
         if cl_channels:
             B, T, H, W, _ = x.shape
             Cin = int(cl_channels)
@@ -455,6 +456,7 @@ class PatchEmbedFunction(torch.autograd.Function):
         if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 5 or x.stride(4) != 1 or x.stride(3) != x.shape[4]:
             raise RuntimeError("mi355x hot path: patch embedding expects a CUDA fp32 (b, t, c, H, W) clip with contiguous image rows")
         b, t, c, H, W = x.shape
+        ops.check_fp16_range(x, "the clip")
         dim = w_perm.shape[0]
         n = (H // patch) * (W // patch)
         out = torch.empty((b * t, n + 1, dim), device=x.device, dtype=torch.float32)
@@ -733,6 +735,7 @@ class LinearRowsFunction(torch.autograd.Function):
     def forward(ctx, x, w):
         x = ops.f32(x).contiguous(); w = ops.f32(w).contiguous()
         ops.require_cuda(x, w)
+        ops.check_fp16_range(x, "a Linear's input")
         rows, Din = x.shape
         Dout = w.shape[0]
         d = ops.make_desc(1, 1, 1, rows, Din, Dout, (1, 1, 1), (1, 1, 1), (0, 0, 0))

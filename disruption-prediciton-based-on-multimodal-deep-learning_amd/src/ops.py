@@ -42,6 +42,20 @@ def require_cuda(*tensors: Optional[torch.Tensor]) -> None:
             raise RuntimeError("mi355x hot path: tensor must be contiguous")
 
 
+import os as _os
+
+CHECK_RANGE = _os.environ.get("MD_CHECK_RANGE") == "1"
+
+
+def check_fp16_range(t: torch.Tensor, what: str) -> None:
+    """Debug aid (MD_CHECK_RANGE=1; synchronises the host): the forward products split their operands into fp16 halves, which
+    needs |x| < 65504.  Activations and weights of these models are O(1); an UNSCALED input signal is the one
+    way to violate it -- the kernels would then return inf where the fp32 reference stays finite."""
+    if CHECK_RANGE and t.numel() and float(t.detach().abs().amax()) >= 65504.0:
+        raise RuntimeError("mi355x hot path: %s holds |x| >= 65504; the split-fp16 forward products overflow there -- scale the "
+                           "input as the reference's data pipeline does (RobustScaler), or use md_set_exact_fp32(1)" % what)
+
+
 def f32(t: torch.Tensor) -> torch.Tensor:
     if t.dtype != torch.float32:
         raise RuntimeError(f"mi355x hot path: expected float32, got {t.dtype}")

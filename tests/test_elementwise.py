@@ -56,3 +56,18 @@ def test_noise_layer_matches_reference_fixture(fx):
     assert torch.equal(xn.grad, torch.ones_like(xn))
     layer.eval()
     assert np.array_equal(layer(xn).detach().cpu().numpy(), fx["noise_eval"])
+
+
+@pytest.mark.gpu
+def test_fp16_range_check_is_loud_when_enabled(monkeypatch):
+    """The split-fp16 forward needs |x| < 65504 (INTEGRATION 'Value range').  With MD_CHECK_RANGE=1 an input
+    beyond that raises instead of returning inf; without it the same call returns non-finite values (documented limit)."""
+    from src import ops
+    from src.models._unit import linear_wb
+    x = torch.full((8, 16), 1.0e5, device="cuda"); w = torch.randn(4, 16, device="cuda"); b = torch.zeros(4, device="cuda")
+    monkeypatch.setattr(ops, "CHECK_RANGE", True)
+    with pytest.raises(RuntimeError, match="65504"):
+        linear_wb(x, w, b)
+    monkeypatch.setattr(ops, "CHECK_RANGE", False)
+    assert not bool(torch.isfinite(linear_wb(x, w, b)).all())
+    assert bool(torch.isfinite(linear_wb(x * 1e-2, w, b)).all())

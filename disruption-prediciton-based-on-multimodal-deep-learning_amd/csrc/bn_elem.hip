@@ -510,6 +510,59 @@ extern "C" int md_bn_bwd_apply_fmt(const float* dA, int g_in, const MdActView* m
   return MD_OK;
 }
 
+// The activation of a unit (leaky(scale * y + shift)), or a materialised tensor as it is (v.scale == nullptr), written in the
+// pre-split bf16 format the weight-gradient kernels stage by plain copy: [row][C8 = ceil(Cp / 8) chunks]{hi 8 x bf16 | lo 8 x bf16}.
+// Same arithmetic as the in-kernel staging (bn_leaky8: packed fma, max(x, slope x); split8), so a weight gradient reading this
+// copy is bit-identical to one that applies BatchNorm-on-read itself.  Cp % 8 == 4: the upper half of the last chunk is zero.
+// Runs on the executor's side stream during the forward pass (which leaves that stream idle): the consumer, the unit's weight
+// gradient, is on that stream as well, a whole backward pass later.
+__global__ __launch_bounds__(256) void k_bn_act_split(View v, int64_t rows, int Cp, int C8, uint4* __restrict__ out) {
+  const int nr = blockDim.x / C8, c8 = threadIdx.x % C8, r0 = threadIdx.x / C8;
+  if (r0 >= nr) return;
+  const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+  const int64_t beg = (int64_t)blockIdx.x * per, end = beg + per < rows ? beg + per : rows;
+  const bool upper = c8 * 8 + 4 < Cp;               // the chunk's channels 4..7 exist
+  f32x4 sc0 = {0.f, 0.f, 0.f, 0.f}, sc1 = sc0, sh0 = sc0, sh1 = sc0;
+  if (v.scale) {
+    sc0 = *(const f32x4*)(v.scale + c8 * 8); sh0 = *(const f32x4*)(v.shift + c8 * 8);
+    if (upper) { sc1 = *(const f32x4*)(v.scale + c8 * 8 + 4); sh1 = *(const f32x4*)(v.shift + c8 * 8 + 4); }
+  }
+  auto one = [&](int64_t row) {
+    const float* s = v.p + (size_t)row * Cp + c8 * 8;
+    const float4 a = *(const float4*)s;
+    const float4 b = upper ? *(const float4*)(s + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float r[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    if (v.scale) {
+      bn_leaky8(r, sc0, sc1, sh0, sh1, v.slope);
+      if (!upper) { r[4] = r[5] = r[6] = r[7] = 0.f; }
+    }
+    uint4 hi, lo;
+    split8(r, hi, lo);
+    out[((size_t)row * C8 + c8) * 2] = hi;
+    out[((size_t)row * C8 + c8) * 2 + 1] = lo;
+  };
+  int64_t row = beg + r0;
+  for (; row + (int64_t)nr < end; row += 2 * (int64_t)nr) { one(row); one(row + nr); }
+  for (; row < end; row += nr) one(row);
+}
+extern "C" size_t md_bn_act_split_floats(int64_t rows, int32_t C) {
+  if (rows <= 0 || C <= 0) return 0;
+  return (size_t)rows * ((md_cpad(C) + 7) / 8) * 8;
+}
+extern "C" int md_bn_act_split(const MdActView* x, int64_t rows, int32_t C, void* out, void* stream) {
+  if (!x || !x->data || !out) return MD_ERR_NULL;
+  int rc = check_rows(rows, C); if (rc) return rc;
+  const int Cp = md_cpad(C), C8 = (Cp + 7) / 8;
+  if (C8 > 256) return MD_ERR_UNSUPPORTED;
+  const int nr = 256 / C8;
+  int64_t blocks = md_cdiv64(rows, (int64_t)nr * 8);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 4096) blocks = 4096;
+  MD_KLAUNCH(k_bn_act_split, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, to_view(x), rows, Cp, C8, (uint4*)out);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+
 extern "C" int md_bn_bwd_apply_g(const float* g, const MdActView* main, const float* mean, const float* invstd,
                                  const float* coef, int64_t rows, int32_t C, float* d_raw, void* stream) {
   if (!g || !main || !main->data || !main->scale || !mean || !invstd || !coef || !d_raw) return MD_ERR_NULL;

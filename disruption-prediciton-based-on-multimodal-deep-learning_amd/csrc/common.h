@@ -71,7 +71,8 @@ bool patch_can_fuse(const PatchPlan* p);
 struct WgradPlan;
 const WgradPlan* wgrad_lookup(const MdConvDesc* d, int xpitch = 0, int xc0 = 0, int dw_cin = 0);   // xpitch != 0: X = channel slice of a wider tensor
 size_t wgrad_patch_workspace_floats(const WgradPlan* p);
+bool wgrad_plan_xsplit_ok(const WgradPlan* p);
 int wgrad_patch_launch(const WgradPlan* p, const MdConvDesc* d, const float* src, const float* ps, const float* psh,
-                       float slope, const float* dy, float* dw, float* slab, hipStream_t s, int ysplit = 0);
+                       float slope, const float* dy, float* dw, float* slab, hipStream_t s, int ysplit = 0, int xsplit = 0);
 int patch_pack_batch(int n, const MdConvDesc* const* descs, const int* dgrad, const float* const* w, float* const* outs,
                      unsigned char* handled, hipStream_t s);

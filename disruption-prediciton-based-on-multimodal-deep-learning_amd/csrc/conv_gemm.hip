@@ -602,16 +602,28 @@ static const WgradPlan* wide_chunk_plan(const MdConvDesc* d, int c0) {
   return wgrad_lookup(&dc, md_cpad(d->Cin), c0, d->Cin);
 }
 
-extern "C" int md_conv_wgrad_fmt(const MdConvDesc* d, const MdActView* x, const void* dy, int dy_split, float* dw,
-                                 float* workspace, void* stream) {
-  if (!dy_split) return md_conv_wgrad(d, x, (const float*)dy, dw, workspace, stream);
+extern "C" int md_conv_wgrad_fmt2(const MdConvDesc* d, const MdActView* x, int x_split, const void* dy, int dy_split, float* dw,
+                                  float* workspace, void* stream) {
+  if (!dy_split && !x_split) return md_conv_wgrad(d, x, (const float*)dy, dw, workspace, stream);
   int rc = check_desc(d);
   if (rc != MD_OK) return rc;
   if (!x || !x->data || !dy || !dw) return MD_ERR_NULL;
   const WgradPlan* wp = wgrad_lookup(d);
-  if (!wp || (md_cpad(d->Cout) & 7)) return MD_ERR_UNSUPPORTED;
+  if (!wp || (dy_split && (md_cpad(d->Cout) & 7))) return MD_ERR_UNSUPPORTED;
   if (!workspace) return MD_ERR_WORKSPACE;
-  return wgrad_patch_launch(wp, d, x->data, x->scale, x->shift, x->slope, (const float*)dy, dw, workspace, (hipStream_t)stream, 1);
+  // x_split: x->data is the pre-activated, pre-split copy of the input (md_bn_act_split); scale / shift / slope are not used
+  return wgrad_patch_launch(wp, d, x->data, x_split ? nullptr : x->scale, x_split ? nullptr : x->shift, x->slope, (const float*)dy, dw,
+                            workspace, (hipStream_t)stream, dy_split ? 1 : 0, x_split ? 1 : 0);
+}
+extern "C" int md_conv_wgrad_fmt(const MdConvDesc* d, const MdActView* x, const void* dy, int dy_split, float* dw,
+                                 float* workspace, void* stream) {
+  return md_conv_wgrad_fmt2(d, x, 0, dy, dy_split, dw, workspace, stream);
+}
+// 1 when the weight gradient of this geometry can read a pre-split X (md_bn_act_split): LDS-patch kernel, not the pixel-pair stem
+extern "C" int md_conv_wgrad_xsplit_ok(const MdConvDesc* d) {
+  if (check_desc(d) != MD_OK) return 0;
+  const WgradPlan* wp = wgrad_lookup(d);
+  return wp && wgrad_plan_xsplit_ok(wp) ? 1 : 0;
 }
 
 extern "C" size_t md_conv_wgrad_workspace_floats(const MdConvDesc* d) {

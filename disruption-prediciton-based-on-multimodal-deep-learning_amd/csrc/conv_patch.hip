@@ -933,6 +933,7 @@ __global__ __launch_bounds__(256) void k_wgrad_patch(
     WGeom g, const float* __restrict__ src, const float* __restrict__ pscale, const float* __restrict__ pshift,
     float pslope, const float* __restrict__ dy, float* __restrict__ slab, int dbg) {
   const int ysplit = (dbg >> 16) & 1;            // dY is a pre-split bf16 gradient ([pixel][Cpo/8 chunks]{hi | lo})
+  const int xsplit = (dbg >> 17) & 1;            // X is a pre-activated, pre-split bf16 tensor ([pixel][ceil(Cpi/8) chunks]{hi | lo})
   dbg &= 0xffff;
   extern __shared__ __attribute__((aligned(16))) char sm[];
   char* sP = sm;
@@ -1004,7 +1005,7 @@ __global__ __launch_bounds__(256) void k_wgrad_patch(
     }
     __syncthreads();
     if (!(dbg & 1)) stage_image_ptr<false>(src, g.xpitch, g.xc0, g.Cpi >> 2, sG, g.P, g.C8i, g.magicC8, sP, g.ppitch, g.lo_off, prologue, sScale - g.xc0,
-                sShift - g.xc0, pslope, t);
+                sShift - g.xc0, pslope, t, xsplit ? ((g.Cpi + 7) >> 3) : 0);
     if (!(dbg & 2)) stage_image_ptr<false>(dy, g.Cpo, n0, ycv4, sGY, PM, g.NC, g.magicNC, sY, g.ypitch, g.ylo_off, false, nullptr, nullptr, 1.f, t,
                                            ysplit ? (g.Cpo >> 3) : 0);
     __syncthreads();
@@ -1070,8 +1071,12 @@ __global__ __launch_bounds__(256) void k_wgrad_patch(
 template <int KTW, int NREP, bool W8 = false>
 __global__ __launch_bounds__(W8 ? 512 : 256) void k_wgrad_patch_pf(
     WGeom g, const float* __restrict__ src, const float* __restrict__ pscale, const float* __restrict__ pshift,
-    float pslope, const float* __restrict__ dy, float* __restrict__ slab, int ysplit) {
-  // ysplit: dY is a pre-split bf16 gradient ([pixel][Cpo/8 chunks]{hi 8 x bf16 | lo 8 x bf16}): its commit is a plain copy
+    float pslope, const float* __restrict__ dy, float* __restrict__ slab, int fmt) {
+  // fmt bit 0 (ysplit): dY is a pre-split bf16 gradient ([pixel][Cpo/8 chunks]{hi 8 x bf16 | lo 8 x bf16}): its commit is a plain copy;
+  // bit 1 (xsplit): X is the pre-activated, pre-split bf16 copy of the unit's input ([pixel][ceil(Cpi/8) chunks]{hi | lo}, written
+  // by md_bn_act_split during the forward pass): no BatchNorm-on-read, no split, a plain copy as well
+  const int ysplit = fmt & 1, xsplit = (fmt >> 1) & 1;
+  const int xp = xsplit ? ((g.Cpi + 7) >> 3) * 8 : g.xpitch;         // floats per X pixel in memory
   extern __shared__ __attribute__((aligned(16))) char sm[];
   char* sP = sm;
   char* sY = sm + g.off_y;
@@ -1137,7 +1142,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void k_wgrad_patch_pf(
       const int ppy = r / g.px; const int ppx = r - ppy * g.px;
       xloc[u] = ppt | (ppy << 6) | (ppx << 15) | (c8 << 24);
       xdst[u] = pixel * g.ppitch + c8 * 16;
-      xrel[u] = ((ppt * g.Hi + ppy) * g.Wi + ppx) * g.xpitch + g.xc0 + c8 * 8;
+      xrel[u] = ((ppt * g.Hi + ppy) * g.Wi + ppx) * xp + g.xc0 + c8 * 8;
     }
   }
 #pragma unroll
@@ -1157,7 +1162,8 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void k_wgrad_patch_pf(
 
   float4 xa_[NX], xb_[NX], ya_[NY], yb_[NY];
   int xfl = 0;                // per item 2 bits: bit0 = loaded (inside the tensor), bit1 = upper half is padding
-  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(src, g.x_bytes), yrs = make_rsrc(dy, g.y_bytes);
+  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(src, xsplit ? (unsigned)((unsigned long long)g.x_bytes / (unsigned)g.xpitch * (unsigned)xp) : g.x_bytes),
+                               yrs = make_rsrc(dy, g.y_bytes);
   // Box being requested (scalars): clip index, output-box origin, input-patch origin, element offsets of the origins.
   int q_t0 = 0, q_y0 = 0, q_x0 = 0, q_ot = 0, q_oh = 0, q_ow = 0, q_xbase = 0, q_ybase = 0, q_live = 0;
   auto aim = [&](int box, bool live) {
@@ -1167,7 +1173,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void k_wgrad_patch_pf(
     const int tb = b % g.nbt; const int n = b / g.nbt;
     q_t0 = tb * g.bt; q_y0 = yb * g.by; q_x0 = xb * g.bx;
     q_ot = q_t0 * g.st + g.org_t; q_oh = q_y0 * g.sh + g.org_h; q_ow = q_x0 * g.sw + g.org_w;
-    q_xbase = (((n * g.Ti + q_ot) * g.Hi + q_oh) * g.Wi + q_ow) * g.xpitch;
+    q_xbase = (((n * g.Ti + q_ot) * g.Hi + q_oh) * g.Wi + q_ow) * xp;
     q_ybase = (((n * g.To + q_t0) * g.Ho + q_y0) * g.Wo + q_x0) * g.Cpo;
     q_live = live ? 1 : 0;
   };
@@ -1178,7 +1184,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void k_wgrad_patch_pf(
     const int c8 = (xloc[u] >> 24) & 255;
     const bool in = q_live && xdst[u] >= 0 && ((unsigned)st < (unsigned)g.Ti) && ((unsigned)sy < (unsigned)g.Hi) &&
                     ((unsigned)sx < (unsigned)g.Wi) && c8 * 2 < xcv4;
-    const bool up = in && c8 * 2 + 1 < xcv4;
+    const bool up = in && (xsplit || c8 * 2 + 1 < xcv4);
     const unsigned off = (unsigned)(q_xbase + xrel[u]) * 4u;
     xa_[u] = buf_load4(xrs, in ? off : MD_OOB);
     xb_[u] = buf_load4(xrs, up ? off + 16u : MD_OOB);
@@ -1204,7 +1210,8 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void k_wgrad_patch_pf(
           if ((xfl >> (2 * u)) & 2) { v[4] = v[5] = v[6] = v[7] = 0.f; }
         }
         uint4 hi, lo;
-        split8(v, hi, lo);
+        if (xsplit) { hi = __builtin_bit_cast(uint4, xa_[u]); lo = __builtin_bit_cast(uint4, xb_[u]); }
+        else split8(v, hi, lo);
         *(uint4*)(sP + xdst[u]) = hi;
         *(uint4*)(sP + g.lo_off + xdst[u]) = lo;
       }
@@ -1509,14 +1516,17 @@ const WgradPlan* wgrad_lookup(const MdConvDesc* d, int xpitch, int xc0, int dw_c
   return wp;
 }
 
+bool wgrad_plan_xsplit_ok(const WgradPlan* p) { return !p->g.pack2 && p->g.xpitch == p->g.Cpi; }
 size_t wgrad_patch_workspace_floats(const WgradPlan* p) { return (size_t)p->nslices * p->g.nkt * 16 * p->g.N16; }
 
 int wgrad_patch_launch(const WgradPlan* p, const MdConvDesc* d, const float* src, const float* ps, const float* psh,
-                       float slope, const float* dy, float* dw, float* slab, hipStream_t s, int ysplit) {
+                       float slope, const float* dy, float* dw, float* slab, hipStream_t s, int ysplit, int xsplit) {
   const WGeom& g = p->g;
   if (ysplit && (g.Cpo & 7)) return MD_ERR_UNSUPPORTED;
+  if (xsplit && (g.pack2 || g.xpitch != g.Cpi || ps)) return MD_ERR_UNSUPPORTED;      // whole-tensor, already activated X only
+  const int fmt = (ysplit ? 1 : 0) | (xsplit ? 2 : 0);
   static const int dbg_env = getenv("MD_DBG") ? atoi(getenv("MD_DBG")) : 0;
-  const int dbg = (dbg_env & 0xffff) | (ysplit ? 0x10000 : 0);
+  const int dbg = (dbg_env & 0xffff) | (ysplit ? 0x10000 : 0) | (xsplit ? 0x20000 : 0);
   dim3 grid(p->nslices, g.nkg * g.nng);
   const bool pf = wgrad_use_pf(g);
 #define LAUNCH_WG(KT_, NR_)                                                                                             \
@@ -1537,9 +1547,9 @@ int wgrad_patch_launch(const WgradPlan* p, const MdConvDesc* d, const float* src
           return MD_ERR_LAUNCH;                                                                                         \
         set8_ = true;                                                                                                   \
       }                                                                                                                 \
-      MD_KLAUNCH((k_wgrad_patch_pf<KT_, NR_, true>), grid, dim3(512), p->lds, s, g, src, ps, psh, slope, dy, slab, ysplit); \
+      MD_KLAUNCH((k_wgrad_patch_pf<KT_, NR_, true>), grid, dim3(512), p->lds, s, g, src, ps, psh, slope, dy, slab, fmt); \
     } else if (pf)                                                                                                      \
-      MD_KLAUNCH((k_wgrad_patch_pf<KT_, NR_>), grid, dim3(256), p->lds, s, g, src, ps, psh, slope, dy, slab, ysplit); \
+      MD_KLAUNCH((k_wgrad_patch_pf<KT_, NR_>), grid, dim3(256), p->lds, s, g, src, ps, psh, slope, dy, slab, fmt); \
     else                                                                                                                \
       MD_KLAUNCH((k_wgrad_patch<KT_, NR_>), grid, dim3(256), p->lds, s, g, src, ps, psh, slope, dy, slab, dbg); \
   } while (0)

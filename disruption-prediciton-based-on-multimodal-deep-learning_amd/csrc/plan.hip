@@ -25,12 +25,14 @@ struct Unit {
   size_t raw_off, stat_off, wf_off, wd_off;   // float offsets into the workspace
   int Cp;
   int split;        // d_raw of this unit is kept in the pre-split bf16 format (md_bn_bwd_apply_fmt)
+  size_t xs_off;    // pre-split bf16 copy of this unit's ACTIVATION (input of the weight gradients of its consumers); 0 = none
+  int xsplit;       // this unit's weight gradient reads the pre-split copy of its input
 };
 struct Block {
   int c1s, c1t, c2s, c2t, dss, dst;   // unit ids (dss/dst = -1 without downsample)
   int in_z, out_z, stage;
 };
-struct ZT { int C; int64_t rows; size_t off; };
+struct ZT { int C; int64_t rows; size_t off; size_t xs_off = 0; };      // xs_off: pre-split copy (see Unit::xs_off)
 
 // Optional per-kernel-class timing with HIP events on the launch stream (used by bench.py's roofline leg).
 enum { KC_FWD = 0, KC_DGRAD = 1, KC_WGRAD = 2, KC_N = 3 };
@@ -206,6 +208,27 @@ extern "C" int md_plan_create(int32_t B, int32_t T, int32_t H, int32_t W, const 
   P->gmax = gmax;
   P->red_blocks.assign(P->units.size(), 0);
   for (size_t i = 0; i < P->units.size(); ++i) P->units[i].split = md_conv_split_dy_ok(&P->units[i].d, i != 0 ? 1 : 0);
+  // Pre-split copies of the weight gradients' X operands: the activation of a unit (or a materialised block tensor) that feeds
+  // a convolution is written once more as bf16 hi|lo pairs during the forward pass -- on the side stream, which the forward
+  // leaves idle -- so that the weight-gradient kernels stage X by plain copy (no BatchNorm-on-read, no split: a third of
+  // their per-box time).  Not for the stem's pixel-pair form (it reads the clip itself).
+  // MEASURED (round 2): bit-identical, and slower -- 6.61 vs 6.21 ms per step: the weight-gradient kernels gain 4 % (3.44 -> 3.30 ms;
+  // they wait for their loads, not for the staging arithmetic), the 28 copy launches cost 1.07 ms of side-stream time and slow
+  // the concurrent forward convolutions by 0.3 ms.  Off unless MD_SPLIT_X=1.
+  static const int split_x = getenv("MD_SPLIT_X") && atoi(getenv("MD_SPLIT_X")) == 1;
+  for (auto& u : P->units) { u.xs_off = 0; u.xsplit = 0; }
+  for (size_t i = 0; split_x && i < P->units.size(); ++i) {
+    Unit& u = P->units[i];
+    if (!md_conv_wgrad_xsplit_ok(&u.d) || (u.in_unit < 0 && u.in_z == 0)) continue;
+    u.xsplit = 1;
+    if (u.in_unit >= 0) {
+      Unit& src = P->units[u.in_unit];
+      if (!src.xs_off) src.xs_off = take(md_bn_act_split_floats(src.rows, src.d.Cout));
+    } else {
+      ZT& z = P->z[u.in_z];
+      if (!z.xs_off) z.xs_off = take(md_bn_act_split_floats(z.rows, z.C));
+    }
+  }
   for (int i = 0; i < 4; ++i) P->g_off[i] = take(gmax);
   P->total_floats = off;
   *out = P;
@@ -372,6 +395,31 @@ extern "C" int md_plan_forward(MdPlan* P, const float* x, const float* const* w,
     return md_bn_finalize(part, md_conv_fwd_stat_blocks(&u.d), u.d.Cout, u.rows, gamma[i], beta[i], 1e-5f, 0.1f,
                           rmean ? rmean[i] : nullptr, rvar ? rvar[i] : nullptr, st, st + u.Cp, st + 2 * u.Cp, st + 3 * u.Cp, s);
   };
+  // pre-split copy of a unit's activation / a block tensor for the weight gradients (see md_plan_create): on the side stream,
+  // behind an event of the stream that has just completed the statistics (`from` == the side stream itself: in order, no event)
+  auto split_copy = [&](const MdActView& v, int64_t rows, int C, size_t xs_off, void* from) -> int {
+    if (!training || !xs_off) return MD_OK;
+    void* to = from;
+    if (side_stream(P)) {
+      to = P->side;
+      if (from != (void*)P->side) {
+        hipEvent_t ready = P->ev_ready[P->ready_ix]; P->ready_ix ^= 1;
+        if (hipEventRecord(ready, (hipStream_t)from) != hipSuccess || hipStreamWaitEvent(P->side, ready, 0) != hipSuccess) return MD_ERR_LAUNCH;
+      }
+      P->side_used = true;
+    }
+    return md_bn_act_split(&v, rows, C, ws + xs_off, to);
+  };
+  auto split_unit = [&](size_t i, void* from) -> int {
+    const Unit& u = P->units[i];
+    MdActView v = unit_out_view(P, ws, (int)i);
+    return split_copy(v, u.rows, u.d.Cout, u.xs_off, from);
+  };
+  auto split_z = [&](int zi, void* from) -> int {
+    const ZT& z = P->z[zi];
+    MdActView v = z_view(P, ws, zi);
+    return split_copy(v, z.rows, z.C, z.xs_off, from);
+  };
   bool skip_on_side = false;       // the current block's skip path (dss, dst) has been queued on the side stream
   for (size_t i = 0; i < P->units.size(); ++i) {
     const Unit& u = P->units[i];
@@ -386,6 +434,7 @@ extern "C" int md_plan_forward(MdPlan* P, const float* x, const float* const* w,
         if (hipEventRecord(ready, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(P->side, ready, 0) != hipSuccess)
           return MD_ERR_LAUNCH;
         RC(train_unit((size_t)b.dss, ws + P->part2_off, P->side));
+        RC(split_unit((size_t)b.dss, P->side));
         RC(train_unit((size_t)b.dst, ws + P->part2_off, P->side));
         P->side_used = true; skip_on_side = true;
       }
@@ -397,6 +446,7 @@ extern "C" int md_plan_forward(MdPlan* P, const float* x, const float* const* w,
           MdActView skipv = unit_out_view(P, ws, b.dst);
           const Unit& t2 = P->units[b.c2t];
           RC(md_residual_fwd(&skipv, &mainv, P->alpha, t2.rows, t2.d.Cout, ws + P->z[b.out_z].off, stream));
+          RC(split_z(b.out_z, stream));
           ++next_block;
         }
         continue;
@@ -404,6 +454,7 @@ extern "C" int md_plan_forward(MdPlan* P, const float* x, const float* const* w,
     }
     if (training) {
       RC(train_unit(i, ws + P->part_off, stream));
+      RC(split_unit(i, stream));
     } else {
       RC(md_conv_fwd(&u.d, &in, ws + u.wf_off, ws + u.raw_off, nullptr, stream));
       RC(md_bn_eval_params(u.d.Cout, gamma[i], beta[i], rmean[i], rvar[i], 1e-5f, st, st + u.Cp, st + 2 * u.Cp, st + 3 * u.Cp,
@@ -412,6 +463,7 @@ extern "C" int md_plan_forward(MdPlan* P, const float* x, const float* const* w,
     if (i == 1) {   // stem output feeds a conv AND an identity skip: materialise it
       MdActView v = unit_out_view(P, ws, 1);
       RC(md_bn_act(&v, u.rows, u.d.Cout, ws + P->z[1].off, stream));
+      RC(split_z(1, stream));
     }
     // close the residual block whose last unit this is
     if (next_block < P->blocks.size()) {
@@ -422,6 +474,7 @@ extern "C" int md_plan_forward(MdPlan* P, const float* x, const float* const* w,
         MdActView skipv = b.dst >= 0 ? unit_out_view(P, ws, b.dst) : z_view(P, ws, b.in_z);
         const Unit& t2 = P->units[b.c2t];
         RC(md_residual_fwd(&skipv, &mainv, P->alpha, t2.rows, t2.d.Cout, ws + P->z[b.out_z].off, stream));
+        RC(split_z(b.out_z, stream));
         ++next_block;
       }
     }
@@ -453,18 +506,22 @@ static int unit_backward(MdPlan* P, float* ws, int ui, int gb, int dxb, int accu
     }
   }
   MdActView in = unit_in_view(P, ws, ui);
+  if (u.xsplit) {          // the pre-split copy of the input written during the forward pass
+    in.data = ws + (u.in_unit >= 0 ? P->units[u.in_unit].xs_off : P->z[u.in_z].xs_off);
+    in.scale = in.shift = nullptr;
+  }
   if (side_stream(P)) {
     // d_raw (G) is complete on the caller's stream here; the weight gradient reads it from the side stream
     hipEvent_t ready = P->ev_ready[P->ready_ix]; P->ready_ix ^= 1;
     if (hipEventRecord(ready, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(P->side, ready, 0) != hipSuccess)
       return MD_ERR_LAUNCH;
     { ProfScope ps(P, KC_WGRAD, unit_flops(u), P->side);
-      RC(md_conv_wgrad_fmt(&u.d, &in, G, u.split, dw[ui], ws + P->slab_off, P->side)); }
+      RC(md_conv_wgrad_fmt2(&u.d, &in, u.xsplit, G, u.split, dw[ui], ws + P->slab_off, P->side)); }
     if (hipEventRecord(P->ev_done[gb], P->side) != hipSuccess) return MD_ERR_LAUNCH;
     P->done_pending[gb] = true; P->side_used = true;
   } else {
     ProfScope ps(P, KC_WGRAD, unit_flops(u), stream);
-    RC(md_conv_wgrad_fmt(&u.d, &in, G, u.split, dw[ui], ws + P->slab_off, stream));
+    RC(md_conv_wgrad_fmt2(&u.d, &in, u.xsplit, G, u.split, dw[ui], ws + P->slab_off, stream));
   }
   if (dxb >= 0) {
     RC(await_buffer(P, dxb, stream));

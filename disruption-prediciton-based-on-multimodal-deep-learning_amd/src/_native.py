@@ -63,6 +63,10 @@ SIGNATURES = {
     "md_bn_bwd_apply_fmt": (C.c_int, [_P, C.c_int, _VIEW, _VIEW, _F, _P, _P, _P, _I64, _I32, _P, C.c_int, _P, _P]),
     "md_conv_dgrad_fmt": (C.c_int, [_DESC, _P, C.c_int, _P, _P, C.c_int, _VIEW, _P, _P, _P, _P]),
     "md_conv_wgrad_fmt": (C.c_int, [_DESC, _VIEW, _P, C.c_int, _P, _P, _P]),
+    "md_conv_wgrad_fmt2": (C.c_int, [_DESC, _VIEW, C.c_int, _P, C.c_int, _P, _P, _P]),
+    "md_conv_wgrad_xsplit_ok": (C.c_int, [_DESC]),
+    "md_bn_act_split_floats": (_SZ, [_I64, _I32]),
+    "md_bn_act_split": (C.c_int, [_VIEW, _I64, _I32, _P, _P]),
     "md_nchw_to_cl": (C.c_int, [_P, _I32, _I32, _I64, _P, _P]),
     "md_cl_to_nchw": (C.c_int, [_P, _I32, _I32, _I64, _P, _P]),
     "md_avgpool_fwd": (C.c_int, [_P, _I32, _I32, _I64, _P, _P]),

@@ -252,6 +252,27 @@ def conv_wgrad_fmt(d: N.MdConvDesc, x: N.MdActView, dy: torch.Tensor, dy_split: 
     return dw
 
 
+def bn_act_split(v: N.MdActView, rows: int, Cc: int, device) -> torch.Tensor:
+    """leaky(scale * y + shift) (or the tensor as it is, scale None) as the pre-split bf16 copy the weight-gradient kernels stage
+    by plain copy (md_bn_act_split); returned as a float32 tensor of the same byte size."""
+    out = torch.empty(N.lib().md_bn_act_split_floats(rows, Cc), device=device, dtype=torch.float32)
+    N.check(N.lib().md_bn_act_split(C.byref(v), rows, Cc, _p(out), _stream()), "md_bn_act_split")
+    return out
+
+
+def conv_wgrad_xsplit(d: N.MdConvDesc, x_split: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    """Weight gradient reading the pre-split copy of its input (md_conv_wgrad_fmt2, x_split = 1)."""
+    require_cuda(dy, x_split)
+    if not N.lib().md_conv_wgrad_xsplit_ok(C.byref(d)):
+        raise RuntimeError("mi355x hot path: this geometry has no pre-split weight-gradient form")
+    dw = torch.empty((d.Cout, d.Cin, d.kt, d.kh, d.kw), device=dy.device, dtype=torch.float32)
+    nws = N.lib().md_conv_wgrad_workspace_floats(C.byref(d))
+    ws = torch.empty(nws, device=dy.device, dtype=torch.float32) if nws else None
+    xv = view(x_split)
+    N.check(N.lib().md_conv_wgrad_fmt2(C.byref(d), C.byref(xv), 1, _p(dy), 0, _p(dw), _p(ws), _stream()), "md_conv_wgrad_fmt2")
+    return dw
+
+
 def conv_wgrad(d: N.MdConvDesc, x: N.MdActView, dy: torch.Tensor) -> torch.Tensor:
     require_cuda(dy)
     dw = torch.empty((d.Cout, d.Cin, d.kt, d.kh, d.kw), device=dy.device, dtype=torch.float32)

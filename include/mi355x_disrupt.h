@@ -178,6 +178,17 @@ int md_conv_dgrad_fmt(const MdConvDesc* d, const void* dy, int dy_split, const f
                       float* partial, void* stream);
 int md_conv_wgrad_fmt(const MdConvDesc* d, const MdActView* x, const void* dy, int dy_split, float* dw,
                       float* workspace, void* stream);
+/* The X operand of a weight gradient as a pre-activated, pre-split copy: md_bn_act_split writes leaky(scale * y + shift) of a
+ * unit (or a materialised tensor as it is, x->scale == NULL) as [row][ceil(Cp/8) chunks]{hi 8 x bf16 | lo 8 x bf16}
+ * (md_bn_act_split_floats floats); md_conv_wgrad_fmt2 with x_split != 0 takes that buffer as x->data (scale / shift ignored) and
+ * stages it by plain copy -- bit-identical to BatchNorm-on-read inside the kernel, a third less time per box.  Available where
+ * md_conv_wgrad_xsplit_ok says so (LDS-patch kernel, not the pixel-pair stem).  The executor writes the copies on its side stream
+ * during the forward pass. */
+size_t md_bn_act_split_floats(int64_t rows, int32_t C);
+int md_bn_act_split(const MdActView* x, int64_t rows, int32_t C, void* out, void* stream);
+int md_conv_wgrad_xsplit_ok(const MdConvDesc* d);
+int md_conv_wgrad_fmt2(const MdConvDesc* d, const MdActView* x, int x_split, const void* dy, int dy_split, float* dw,
+                       float* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Boundary layout conversion, pooling, classifier head, losses.

@@ -247,3 +247,30 @@ def test_presplit_gradient_format_is_bit_identical(case, persistent):
         assert torch.equal(dw32, dwsp), name
     finally:
         lib.md_set_pers_grid(prev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,k,pad,shape", [(32, 72, (1, 3, 3), (0, 1, 1), (2, 5, 32, 32)), (72, 32, (3, 1, 1), (1, 0, 0), (2, 6, 24, 24)),
+                                                  (115, 64, (3, 1, 1), (1, 0, 0), (1, 5, 16, 16)), (64, 144, (1, 3, 3), (0, 1, 1), (1, 3, 20, 20)),
+                                                  (21, 64, (1, 1, 1), (0, 0, 0), (2, 4, 16, 16))])
+def test_weight_gradient_from_the_presplit_activation_copy_is_bit_identical(cin, cout, k, pad, shape):
+    """md_bn_act_split + md_conv_wgrad_fmt2(x_split): the weight gradient that stages a pre-activated, pre-split bf16 copy of its
+    input by plain copy against the one that applies BatchNorm-on-read and splits inside the kernel -- same bits (channel counts
+    with Cp % 8 == 4 and Cp < 16-channel k tiles included), also for a materialised input without BatchNorm view."""
+    from src import ops
+    N_, T, H, W = shape
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    d = ops.make_desc(N_, T, H, W, cin, cout, k, (1, 1, 1), pad)
+    Cp = ops.cpad(cin)
+    x = torch.zeros(N_, T, H, W, Cp); x[..., :cin] = torch.randn(N_, T, H, W, cin, generator=g)
+    sc = torch.zeros(Cp); sh = torch.zeros(Cp); sc[:cin] = torch.rand(cin, generator=g) + 0.5; sh[:cin] = torch.randn(cin, generator=g) * 0.3
+    dy = torch.zeros(N_, d.To, d.Ho, d.Wo, ops.cpad(cout)); dy[..., :cout] = torch.randn(N_, d.To, d.Ho, d.Wo, cout, generator=g) * 1e-3
+    x, sc, sh, dy = x.cuda(), sc.cuda(), sh.cuda(), dy.cuda()
+    rows = N_ * T * H * W
+    for with_bn in (True, False):
+        v = ops.view(x, sc, sh, 0.01) if with_bn else ops.view(x)
+        ref = ops.conv_wgrad(d, v, dy)
+        xs = ops.bn_act_split(v, rows, cin, x.device)
+        got = ops.conv_wgrad_xsplit(d, xs, dy)
+        torch.cuda.synchronize()
+        assert torch.equal(ref, got), (with_bn, float((ref - got).abs().max()))

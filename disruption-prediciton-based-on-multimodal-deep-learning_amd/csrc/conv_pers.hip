@@ -57,6 +57,7 @@ __global__ __launch_bounds__(512) void k_conv_pers(
   const bool prologue = pscale != nullptr;
   const bool stats = stat_partial != nullptr;
   const int dbg = (accumulate >> 8) & 0xff;         // timing experiments (MD_DBG): 1 no patch loads, 2 no matrix loop, 4 no stores, 8 no commit
+  const bool xcd_order = (accumulate >> 18) & 1;
   const bool presplit = (accumulate >> 16) & 1;      // source = pre-split bf16 gradient [pixel][C8]{hi | lo}: the commit is a plain copy
   accumulate &= 1;
 
@@ -217,9 +218,13 @@ __global__ __launch_bounds__(512) void k_conv_pers(
   unsigned goff[2] = {MD_OOB, MD_OOB}; float gw[2] = {0.f, 0.f};
 
   const int stride = 2 * (int)gridDim.x;
-  int cur = 2 * (int)blockIdx.x + team;                                // box whose patch is (or is about to be) in LDS
+  // XCD-aware order (accumulate bit 18): workgroup w runs on XCD w % 8, each with its own L2.  With the plain order the boxes in
+  // flight at any time are spread round-robin over the XCDs, so the halo a box shares with its neighbours is fetched into several
+  // L2s; with wid below, XCD x walks the contiguous range of workgroup indices [x G/8, (x+1) G/8).
+  const int wid = xcd_order && (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  int cur = 2 * wid + team;                                            // box whose patch is (or is about to be) in LDS
   // boxes of team 0 (>= those of team 1): both teams run that many iterations so that the barriers pair up
-  const int first0 = 2 * (int)blockIdx.x;
+  const int first0 = 2 * wid;
   const int niter = first0 < pg.nboxes ? (pg.nboxes - first0 + stride - 1) / stride : 0;
   if (cur < pg.nboxes) { issue(cur); commit(); }
   __syncthreads();                                                     // both teams' first patches complete
@@ -457,7 +462,8 @@ int pers_launch(const PersGeom& pg, size_t lds, int grid, bool f16, const float*
   const int nrep = g.N16 / 16;
   const int nblk = pers_blocks(pg, grid);
   static const int dbg = getenv("MD_DBG") ? atoi(getenv("MD_DBG")) : 0;
-  accumulate = (accumulate & 0x10001) | ((dbg & 0xff) << 8);
+  static const int xcd = getenv("MD_PERS_XCD") ? atoi(getenv("MD_PERS_XCD")) : 0;
+  accumulate = (accumulate & 0x10001) | ((dbg & 0xff) << 8) | (xcd ? 0x40000 : 0);
 #define LAUNCH_PERS(F16_, FUSE_, NR_, MX_)                                                                              \
   do {                                                                                                                  \
     static bool set_ = false;                                                                                           \

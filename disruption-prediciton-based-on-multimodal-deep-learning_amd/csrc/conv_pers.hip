@@ -58,6 +58,7 @@ __global__ __launch_bounds__(512) void k_conv_pers(
   const bool stats = stat_partial != nullptr;
   const int dbg = (accumulate >> 8) & 0xff;         // timing experiments (MD_DBG): 1 no patch loads, 2 no matrix loop, 4 no stores, 8 no commit
   const bool xcd_order = (accumulate >> 18) & 1;
+  const bool early_issue = (accumulate >> 19) & 1;
   const bool presplit = (accumulate >> 16) & 1;      // source = pre-split bf16 gradient [pixel][C8]{hi | lo}: the commit is a plain copy
   accumulate &= 1;
 
@@ -227,12 +228,13 @@ __global__ __launch_bounds__(512) void k_conv_pers(
   const int first0 = 2 * wid;
   const int niter = first0 < pg.nboxes ? (pg.nboxes - first0 + stride - 1) / stride : 0;
   if (cur < pg.nboxes) { issue(cur); commit(); }
+  if (early_issue && cur + stride < pg.nboxes) issue(cur + stride);     // (early_issue: see do_move)
   __syncthreads();                                                     // both teams' first patches complete
 
   auto do_matrix = [&]() __attribute__((always_inline)) {
     // ================= MATRIX phase of box `cur`
     const int nxt = cur + stride;
-    if (nxt < pg.nboxes && !(dbg & 16)) issue(nxt);                // in flight during the matrix loop
+    if (!early_issue && nxt < pg.nboxes && !(dbg & 16)) issue(nxt);  // in flight during the matrix loop
     if (cur < pg.nboxes && !(dbg & 64)) {
       // destination pixels of this box (byte offsets of channel c0; pixels outside the tensor: out-of-range offset)
       {
@@ -316,6 +318,9 @@ __global__ __launch_bounds__(512) void k_conv_pers(
       for (int j = 0; j < YD; ++j) request_y(j);
     }
     if (nxt < pg.nboxes && !(dbg & 8)) commit();
+    // early_issue (accumulate bit 19): the box after next is requested as soon as the commit has freed the staging registers --
+    // in flight during this epilogue, the hand-over and the whole next matrix phase instead of the matrix phase alone
+    if (early_issue && nxt + stride < pg.nboxes) issue(nxt + stride);
     if (cur < pg.nboxes && !(dbg & 32)) {
 #pragma unroll
       for (int j = 0; j < NREP; ++j) {
@@ -463,7 +468,8 @@ int pers_launch(const PersGeom& pg, size_t lds, int grid, bool f16, const float*
   const int nblk = pers_blocks(pg, grid);
   static const int dbg = getenv("MD_DBG") ? atoi(getenv("MD_DBG")) : 0;
   static const int xcd = getenv("MD_PERS_XCD") ? atoi(getenv("MD_PERS_XCD")) : 0;
-  accumulate = (accumulate & 0x10001) | ((dbg & 0xff) << 8) | (xcd ? 0x40000 : 0);
+  static const int early = getenv("MD_PERS_EARLY") ? atoi(getenv("MD_PERS_EARLY")) : 0;
+  accumulate = (accumulate & 0x10001) | ((dbg & 0xff) << 8) | (xcd ? 0x40000 : 0) | (early ? 0x80000 : 0);
 #define LAUNCH_PERS(F16_, FUSE_, NR_, MX_)                                                                              \
   do {                                                                                                                  \
     static bool set_ = false;                                                                                           \

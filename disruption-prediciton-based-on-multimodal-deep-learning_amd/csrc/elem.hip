@@ -362,6 +362,22 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_small(const float* __restrict__ x, const float* __restrict__ v, float scale, int A,
                                                int Bn, int Cn, float* __restrict__ out) {
   const int64_t n = MODE == 1 ? (int64_t)A * Cn : (int64_t)A * Bn * Cn;
+  // 16-byte form of the two streaming modes (Linear bias over rows: Cn == 1, Bn % 4 == 0; dropout mask): a float per thread and a
+  // 64-bit division per element made these launches 2-3x slower than the bytes they move
+  if ((MODE == 3 || (MODE == 0 && Cn == 1 && (Bn & 3) == 0)) && (n & 3) == 0 &&
+      ((((uintptr_t)x | (uintptr_t)v | (uintptr_t)out) & 15) == 0)) {
+    const int64_t n4 = n >> 2;
+    const int b4 = Bn >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+      const float4 a = ((const float4*)x)[i];
+      const float4 b = MODE == 3 ? ((const float4*)v)[i] : ((const float4*)v)[i % b4];
+      float4 r;
+      if (MODE == 3) { r.x = a.x * b.x * scale; r.y = a.y * b.y * scale; r.z = a.z * b.z * scale; r.w = a.w * b.w * scale; }
+      else { r.x = a.x + b.x; r.y = a.y + b.y; r.z = a.z + b.z; r.w = a.w + b.w; }
+      ((float4*)out)[i] = r;
+    }
+    return;
+  }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     if (MODE == 3) out[i] = x[i] * v[i] * scale;
     else if (MODE == 0) out[i] = x[i] + v[(i / Cn) % Bn];                  // A = N, Bn = C, Cn = L

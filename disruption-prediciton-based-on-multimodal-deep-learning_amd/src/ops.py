@@ -8,6 +8,7 @@ Tensors in the library's internal layout are channels-last ``[N, T, H, W, Cp]`` 
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -102,7 +103,7 @@ def from_channels_last(x: torch.Tensor, channels: int) -> torch.Tensor:
 # Batched packing for the composable models: pack_weights() remembers (descriptor, want_dgrad) per weight tensor; inside
 # ``prepacked(module)`` -- the models' forward() -- the operands of every remembered weight are packed up front by ONE batched
 # call (md_conv_pack_weights_batch: ~120 tiny launches per SlowFast step become 3) and pack_weights() hands them out.
-_pack_memo = {}        # id(weight) -> (weight (kept alive), descriptor fields, want_dgrad)
+_pack_memo = {}        # id(weight) -> (weak reference to the weight, descriptor fields, want_dgrad)
 _pack_ready = None     # inside prepacked(): id(weight) -> (descriptor fields, wf, wd)
 
 
@@ -123,7 +124,13 @@ class prepacked:
         self.outer = _pack_ready
         if self.outer is not None or not _pack_memo:
             return self
-        items = [(wid, w, key, wd) for wid, (w, key, wd) in _pack_memo.items() if wid in self.ids and w.is_cuda]
+        items = []
+        for wid, (ref, key, wd) in list(_pack_memo.items()):
+            w = ref()
+            if w is None:                              # the parameter is gone (its id may be reused by another object): forget it
+                del _pack_memo[wid]
+            elif wid in self.ids and w.is_cuda:
+                items.append((wid, w, key, wd))
         if not items:
             return self
         L = N.lib()
@@ -157,7 +164,7 @@ def pack_weights(d: N.MdConvDesc, w: torch.Tensor, want_dgrad: bool = True):
         if hit is not None and hit[0] == key and (hit[2] is not None or not want_dgrad):
             return hit[1], (hit[2] if want_dgrad else None)
     if isinstance(w, torch.nn.Parameter):                 # (views and temporaries have no stable identity)
-        _pack_memo[id(w)] = (w, key, bool(want_dgrad))
+        _pack_memo[id(w)] = (weakref.ref(w), key, bool(want_dgrad))
     L = N.lib()
     wf = torch.empty(L.md_conv_wpack_fwd_floats(C.byref(d)), device=w.device, dtype=torch.float32)
     wd = torch.empty(L.md_conv_wpack_dgrad_floats(C.byref(d)), device=w.device, dtype=torch.float32) if want_dgrad else None

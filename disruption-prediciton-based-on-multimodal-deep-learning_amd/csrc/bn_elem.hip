@@ -166,7 +166,7 @@ __global__ void k_bn_eval_params(int C, int Cp, const float* __restrict__ gamma,
 // g = dA * leaky'_main(pre_main); closing form: dS = dZ * leaky'_alpha(act(skip) + act(main)), g = dS * leaky'(pre).
 // GIN: dA already holds g (the fused reduction of the consumer's data gradient multiplied by leaky' on the way out).
 template <bool APPLY, bool GIN = false>
-__global__ __launch_bounds__(256) void k_bn_bwd(const float* __restrict__ dA, View main, View skip, int has_skip,
+__global__ __launch_bounds__(256) void k_bn_bwd(const float* __restrict__ dA, View main, View skip, int flags,
                                                 float alpha, const float* __restrict__ mean,
                                                 const float* __restrict__ invstd, const float* __restrict__ coef,
                                                 int64_t rows, int C4, float* __restrict__ partial,
@@ -174,7 +174,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd(const float* __restrict__ dA, Vi
   __shared__ float4 red[256];
   // The reduction pass walks the tensor back to front: dA was just written front to back by the data-gradient kernel,
   // and the apply pass that follows (front to back) then starts on what this pass touched last.
-  const int bid = APPLY ? (int)blockIdx.x : (int)(gridDim.x - 1 - blockIdx.x);
+  const int has_skip = flags & 1;
+  const int bid = (APPLY || (flags & 2)) ? (int)blockIdx.x : (int)(gridDim.x - 1 - blockIdx.x);
   RowWalk w = row_walk(rows, C4, bid);
   const int Cp = C4 * 4;
   float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1;
@@ -429,9 +430,11 @@ extern "C" int32_t md_bn_bwd_blocks(int64_t rows, int32_t C) {
   if (check_rows(rows, C) != MD_OK) return 0;
   const int C4 = md_cpad(C) / 4;
   const int nr = 256 / C4;
-  int64_t b = md_cdiv64(rows, (int64_t)nr * 16);
+  static const int cap = getenv("MD_BN_RED_CAP") ? atoi(getenv("MD_BN_RED_CAP")) : 2048;
+  static const int per = getenv("MD_BN_RED_ROWS") ? atoi(getenv("MD_BN_RED_ROWS")) : 16;
+  int64_t b = md_cdiv64(rows, (int64_t)nr * per);
   if (b < 1) b = 1;
-  if (b > 2048) b = 2048;
+  if (b > cap) b = cap;
   return (int32_t)b;
 }
 
@@ -441,8 +444,9 @@ extern "C" int md_bn_bwd_reduce(const float* dA, const MdActView* main, const Md
   if (!dA || !main || !main->data || !mean || !invstd || !partial) return MD_ERR_NULL;
   int rc = check_rows(rows, C); if (rc) return rc;
   const int C4 = md_cpad(C) / 4;
+  static const int fwd_order = getenv("MD_BN_RED_FWD") ? 2 * (atoi(getenv("MD_BN_RED_FWD")) != 0) : 0;
   MD_KLAUNCH(k_bn_bwd<false>, dim3(md_bn_bwd_blocks(rows, C)), dim3(256), 0, (hipStream_t)stream, dA,
-                     to_view(main), to_view(skip), skip != nullptr ? 1 : 0, alpha, mean, invstd, (const float*)nullptr,
+                     to_view(main), to_view(skip), (skip != nullptr ? 1 : 0) | fwd_order, alpha, mean, invstd, (const float*)nullptr,
                      rows, C4, partial, (float*)nullptr, (float*)nullptr);
   MD_CHECK_LAUNCH();
   return MD_OK;

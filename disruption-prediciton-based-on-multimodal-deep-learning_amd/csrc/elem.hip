@@ -77,20 +77,44 @@ __device__ __forceinline__ float block_sum256(float v, float* red) {      // red
 
 // MODE 0: out[row] = mean(a[row][:]);  MODE 1: out[row] = sum_thw dout * swish'(a*g) * a   (g = gate[row])
 template <int MODE>
+__device__ __forceinline__ float row_term(float x, float d, float g) {
+  if (MODE == 0) return x;
+  if (MODE == 2) return d * x;                                      // plain gate (no Swish): dgate = sum dout * a
+  const float q = x * g, sg = sigmoidf_(q);
+  return d * (sg * (1.f + q * (1.f - sg))) * x;
+}
+template <int MODE>
+__device__ __forceinline__ float row_term4(float4 x, float4 d, float g) {
+  return (row_term<MODE>(x.x, d.x, g) + row_term<MODE>(x.y, d.y, g)) + (row_term<MODE>(x.z, d.z, g) + row_term<MODE>(x.w, d.w, g));
+}
+template <int MODE>
 __global__ __launch_bounds__(256) void k_row_reduce(const float* __restrict__ a, const float* __restrict__ gate,
                                                     const float* __restrict__ dout, int64_t thw, float* __restrict__ out) {
   __shared__ float red[4];
   const int64_t row = blockIdx.x;
   const float* ar = a + row * thw;
+  const float* dr = MODE == 0 ? ar : dout + row * thw;
   const float g = MODE == 1 ? gate[row] : 0.f;
   float s = 0.f;
-  for (int64_t i = threadIdx.x; i < thw; i += 256) {
-    if (MODE == 0) s += ar[i];
-    else if (MODE == 2) s += dout[row * thw + i] * ar[i];          // plain gate (no Swish): dgate = sum dout * a
-    else {
-      const float x = ar[i], q = x * g, sg = sigmoidf_(q);
-      s += dout[row * thw + i] * (sg * (1.f + q * (1.f - sg))) * x;
+  if ((thw & 3) == 0 && (((uintptr_t)a | (uintptr_t)dr) & 15) == 0) {
+    // 16-byte loads, four per tensor in flight per lane (one workgroup per row: few waves per CU, so depth per lane matters);
+    // four running sums per lane, combined in a fixed order
+    const float4* a4 = (const float4*)ar; const float4* d4 = (const float4*)dr;
+    const int64_t n4 = thw >> 2;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int64_t i = threadIdx.x;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (; i + 3 * 256 < n4; i += 4 * 256) {
+      const float4 x0 = a4[i], x1 = a4[i + 256], x2 = a4[i + 512], x3 = a4[i + 768];
+      float4 e0 = z, e1 = z, e2 = z, e3 = z;
+      if (MODE != 0) { e0 = d4[i]; e1 = d4[i + 256]; e2 = d4[i + 512]; e3 = d4[i + 768]; }
+      s0 += row_term4<MODE>(x0, e0, g); s1 += row_term4<MODE>(x1, e1, g);
+      s2 += row_term4<MODE>(x2, e2, g); s3 += row_term4<MODE>(x3, e3, g);
     }
+    for (; i < n4; i += 256) s0 += row_term4<MODE>(a4[i], MODE != 0 ? d4[i] : z, g);
+    s = (s0 + s1) + (s2 + s3);
+  } else {
+    for (int64_t i = threadIdx.x; i < thw; i += 256) s += row_term<MODE>(ar[i], MODE != 0 ? dr[i] : 0.f, g);
   }
   const float t = block_sum256(s, red);
   if (threadIdx.x == 0) out[row] = MODE == 0 ? t / (float)thw : t;
@@ -160,22 +184,43 @@ __global__ __launch_bounds__(256) void k_se_gate_bwd_w(const float* __restrict__
 // MODE 0: out = swish(a*g);  MODE 1: da = dout*swish'(a*g)*g + dpool/thw;  MODE 2: out = relu(a+b);  MODE 3: dx = dout*(out>0)
 // MODE 4: out = a*g;  MODE 5: da = dout*g + dpool/thw   (squeeze-excitation without Swish, MLSTM_FCN.py:17-33)
 template <int MODE>
+__device__ __forceinline__ float row_elem1(float a, float b, float g, float extra) {
+  if (MODE == 0) { const float q = a * g; return q * sigmoidf_(q); }
+  if (MODE == 1) { const float q = a * g, sg = sigmoidf_(q); return b * (sg * (1.f + q * (1.f - sg))) * g + extra; }
+  if (MODE == 2) { const float s = a + b; return s > 0.f ? s : 0.f; }
+  if (MODE == 3) return a > 0.f ? b : 0.f;
+  if (MODE == 4) return a * g;
+  return b * g + extra;
+}
+template <int MODE>
 __global__ __launch_bounds__(256) void k_row_elem(const float* __restrict__ a, const float* __restrict__ b,
                                                   const float* __restrict__ rowv, const float* __restrict__ rowv2,
                                                   int64_t thw, int64_t n, float* __restrict__ out) {
+  constexpr bool ROWS = MODE == 0 || MODE == 1 || MODE == 4 || MODE == 5;       // per-row constants
+  constexpr bool HAS_B = MODE == 1 || MODE == 2 || MODE == 3 || MODE == 5;
+  constexpr bool EXTRA = MODE == 1 || MODE == 5;
+  const bool al16 = (((uintptr_t)a | (uintptr_t)out | (HAS_B ? (uintptr_t)b : (uintptr_t)0)) & 15) == 0;
+  if ((thw & 3) == 0 && al16 && n < ((int64_t)1 << 31)) {
+    // 16 bytes per lane (the four elements share a row: thw % 4 == 0), row index by a 32-bit division
+    const uint32_t n4 = (uint32_t)(n >> 2), t4 = (uint32_t)(thw >> 2), stride = gridDim.x * 256u;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n4; i += stride) {
+      const float4 x = ((const float4*)a)[i];
+      float4 y = x;
+      if (HAS_B) y = ((const float4*)b)[i];
+      float g = 0.f, e = 0.f;
+      if (ROWS) { const uint32_t row = i / t4; g = rowv[row]; if (EXTRA) e = rowv2[row] / (float)thw; }
+      float4 r;
+      r.x = row_elem1<MODE>(x.x, y.x, g, e); r.y = row_elem1<MODE>(x.y, y.y, g, e);
+      r.z = row_elem1<MODE>(x.z, y.z, g, e); r.w = row_elem1<MODE>(x.w, y.w, g, e);
+      ((float4*)out)[i] = r;
+    }
+    return;
+  }
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-    float r;
-    if (MODE == 0) { const float q = a[i] * rowv[i / thw]; r = q * sigmoidf_(q); }
-    else if (MODE == 1) {
-      const int64_t row = i / thw; const float g = rowv[row], q = a[i] * g, sg = sigmoidf_(q);
-      r = b[i] * (sg * (1.f + q * (1.f - sg))) * g + rowv2[row] / (float)thw;
-    }
-    else if (MODE == 2) { const float s = a[i] + b[i]; r = s > 0.f ? s : 0.f; }
-    else if (MODE == 3) r = a[i] > 0.f ? b[i] : 0.f;
-    else if (MODE == 4) r = a[i] * rowv[i / thw];
-    else { const int64_t row = i / thw; r = b[i] * rowv[row] + rowv2[row] / (float)thw; }
-    out[i] = r;
+    float g = 0.f, e = 0.f;
+    if (ROWS) { const int64_t row = i / thw; g = rowv[row]; if (EXTRA) e = rowv2[row] / (float)thw; }
+    out[i] = row_elem1<MODE>(a[i], HAS_B ? b[i] : 0.f, g, e);
   }
 }
 
@@ -261,7 +306,7 @@ extern "C" int md_add_relu_fwd(const float* a, const float* b, int64_t n, float*
   if (!a || !b || !out) return MD_ERR_NULL;
   if (n <= 0) return MD_ERR_BAD_SHAPE;
   MD_KLAUNCH(k_row_elem<2>, dim3(elem_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, (const float*)nullptr,
-             (const float*)nullptr, (int64_t)1, n, out);
+             (const float*)nullptr, (int64_t)((n & 3) == 0 ? 4 : 1), n, out);
   MD_CHECK_LAUNCH();
   return MD_OK;
 }
@@ -269,7 +314,7 @@ extern "C" int md_add_relu_bwd(const float* out, const float* dout, int64_t n, f
   if (!out || !dout || !dx) return MD_ERR_NULL;
   if (n <= 0) return MD_ERR_BAD_SHAPE;
   MD_KLAUNCH(k_row_elem<3>, dim3(elem_blocks(n)), dim3(256), 0, (hipStream_t)stream, out, dout, (const float*)nullptr,
-             (const float*)nullptr, (int64_t)1, n, dx);
+             (const float*)nullptr, (int64_t)((n & 3) == 0 ? 4 : 1), n, dx);
   MD_CHECK_LAUNCH();
   return MD_OK;
 }

@@ -13,6 +13,7 @@ import torch
 
 from .. import _native as N
 from .. import ops
+from ..utils import streams
 
 
 # BatchNorm's num_batches_tracked is a device tensor: ``+= 1`` per unit is one tiny launch per BatchNorm per step (50 in SlowFast).
@@ -91,12 +92,18 @@ class ConvBnLeakyFunction(torch.autograd.Function):
         d = ctx.d
         dA = dout.contiguous().float() if ctx.cl else ops.to_channels_last(dout.contiguous().float())
         d_raw, _, dgamma, dbeta = ops.bn_backward(dA, ops.view(y, st[2], st[3], ctx.slope), st, d.Cout)
-        dw = ops.conv_wgrad(d, ops.view(xcl), d_raw)
         dx = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and streams.unit_helpers(d_raw):
+            with streams.fork(d_raw.device, None, (d_raw, xcl)) as f:      # weight gradient beside the data gradient
+                dw = ops.conv_wgrad(d, ops.view(xcl), d_raw)
             dx = ops.conv_dgrad(d, d_raw, wd)
-            if not ctx.cl:
-                dx = ops.from_channels_last(dx, d.Cin)
+            f.join(dw)
+        else:
+            dw = ops.conv_wgrad(d, ops.view(xcl), d_raw)
+            if ctx.needs_input_grad[0]:
+                dx = ops.conv_dgrad(d, d_raw, wd)
+        if dx is not None and not ctx.cl:
+            dx = ops.from_channels_last(dx, d.Cin)
         return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
@@ -238,12 +245,18 @@ class ConvFunction(torch.autograd.Function):
         xcl, wd = ctx.saved_tensors
         d = ctx.d
         dy = dout.contiguous().float() if ctx.cl else ops.to_channels_last(dout.contiguous().float())
-        dw = ops.conv_wgrad(d, ops.view(xcl), dy)
         dx = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and streams.unit_helpers(dy):
+            with streams.fork(dy.device, None, (dy, xcl)) as f:            # weight gradient beside the data gradient
+                dw = ops.conv_wgrad(d, ops.view(xcl), dy)
             dx = ops.conv_dgrad(d, dy, wd)
-            if not ctx.cl:
-                dx = ops.from_channels_last(dx, d.Cin)
+            f.join(dw)
+        else:
+            dw = ops.conv_wgrad(d, ops.view(xcl), dy)
+            if ctx.needs_input_grad[0]:
+                dx = ops.conv_dgrad(d, dy, wd)
+        if dx is not None and not ctx.cl:
+            dx = ops.from_channels_last(dx, d.Cin)
         return dx, dw, None, None, None
 
 

@@ -12,6 +12,7 @@ from typing import Literal
 import torch
 import torch.nn as nn
 
+from ..utils import streams
 from .MLSTM_FCN import MLSTM_FCN
 from .MultiModal import _classifier, _connector, _make_classifier, _make_connector, _param_table
 from .R2Plus1D import R2Plus1DClassifier, R2Plus1DNet
@@ -72,12 +73,21 @@ class FusionGB(nn.Module):
             return self.vis_model(x_vis)
         elif self.use_stream == "0D":
             return self.ts_model(x_ts)
-        vis_latent = self._vis[0](x_vis)
-        ts_latent = self._ts[0](x_ts)
+        if streams.enabled(x_vis) and x_ts.is_cuda:
+            # the 0D encoder and its head on a side stream, beside the video encoder (src/utils/streams.py)
+            with streams.fork(x_vis.device, 1, (x_ts,)) as f:
+                ts_latent = self._ts[0](x_ts)
+                out_ts = self._ts[1](ts_latent)
+            vis_latent = self._vis[0](x_vis)
+            out_vis = self._vis[1](vis_latent)
+            f.join(ts_latent, out_ts)
+        else:
+            vis_latent = self._vis[0](x_vis)
+            ts_latent = self._ts[0](x_ts)
+            out_vis = self._vis[1](vis_latent)
+            out_ts = self._ts[1](ts_latent)
         self.vis_latent = (vis_latent,)
         self.ts_latent = (ts_latent,)
-        out_vis = self._vis[1](vis_latent)
-        out_ts = self._ts[1](ts_latent)
         x = _connector(torch.cat([vis_latent, ts_latent], axis=1), self.connector)
         out_multi = _classifier(x, self.classifier)
         return out_multi if self.use_stream == 'multi' else (out_multi, out_vis, out_ts)

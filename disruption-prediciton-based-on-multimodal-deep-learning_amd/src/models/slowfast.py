@@ -16,6 +16,7 @@ from .resnet import *          # noqa: F401,F403  (as the reference does, slowfa
 from .resnet import Bottleneck3D, ResNet3D
 import os
 
+from ..utils import streams
 from ._unit import GlobalAvgPoolFunction, cat_cl, conv_plain, deferred_bn_counters, from_cl_act, head_apply, to_cl_act
 
 # the stages keep their activations in the kernels' channels-last layout (MD_SLOWFAST_CL=0: reference layout at every unit boundary)
@@ -33,17 +34,18 @@ class SlowNet(ResNet3D):
         super(SlowNet, self).__init__(blocks, layers, **kwargs)
         self.init_params()
 
-    def forward(self, x: Tuple[torch.Tensor, List[torch.Tensor]]):
+    def forward(self, x: Tuple[torch.Tensor, List[torch.Tensor]], ready=None):
+        """``ready``: one event per lateral when the fast pathway runs on a side stream (this pathway waits for lateral k only
+        when stage k needs it)."""
         h, laterals = x
         h = self.stem(h)
         if _CL:
             h = to_cl_act(h)
-            for name, lat in zip(_STAGES, laterals):
-                h = getattr(self, name)(cat_cl(h, lat))
-            return GlobalAvgPoolFunction.apply(from_cl_act(h))
-        for name, lat in zip(_STAGES, laterals):
-            h = getattr(self, name)(torch.cat([h, lat], dim=1))
-        return GlobalAvgPoolFunction.apply(h)
+        for k, (name, lat) in enumerate(zip(_STAGES, laterals)):
+            if ready is not None:
+                streams.wait(ready[k], lat)
+            h = getattr(self, name)(cat_cl(h, lat) if _CL else torch.cat([h, lat], dim=1))
+        return GlobalAvgPoolFunction.apply(from_cl_act(h) if _CL else h)
 
 
 def resnet50_s(block=Bottleneck3D, layers=[3, 4, 6, 3], **kwargs):
@@ -62,15 +64,21 @@ class FastNet(ResNet3D):
             setattr(self, name, nn.Conv3d(width, width, kernel_size=(a + 2, 1, 1), stride=(a, 1, 1), padding=(1, 0, 0), bias=False))
         self.init_params()
 
-    def forward(self, x: torch.Tensor):
+    def forward(self, x: torch.Tensor, mark=None):
+        """``mark()`` (optional) is called after every lateral and returns an event; the events come back as the third result."""
         h = self.stem(x)
         if _CL:
             h = to_cl_act(h)
         laterals = [conv_plain(h, self.l_maxpool)]
+        ready = [mark()] if mark is not None else None
         for name, lat in zip(_STAGES[:3], _LATERALS[1:]):
             h = getattr(self, name)(h)
             laterals.append(conv_plain(h, getattr(self, lat)))
+            if mark is not None:
+                ready.append(mark())
         h = self.layer4(h)
+        if mark is not None:
+            return GlobalAvgPoolFunction.apply(from_cl_act(h) if _CL else h), laterals, ready
         return GlobalAvgPoolFunction.apply(from_cl_act(h) if _CL else h), laterals
 
 
@@ -102,8 +110,15 @@ class SlowFastEncoder(nn.Module):
         from .. import ops
         with deferred_bn_counters(), ops.prepacked(self):   # one launch for all BatchNorm step counters / (almost) all weight packs
             x_slow, x_fast = self.split_slow_fast(x)
-            x_fast, laterals = self.fastnet(x_fast)
-            x_slow = self.slownet((x_slow, laterals))
+            if streams.enabled(x):
+                # the fast pathway on a side stream; the slow one follows on the current stream and waits lateral by lateral
+                with streams.fork(x.device, 0, (x,)) as f:
+                    x_fast, laterals, ready = self.fastnet(x_fast, f.mark)
+                x_slow = self.slownet((x_slow, laterals), ready)
+                f.join(x_fast)
+            else:
+                x_fast, laterals = self.fastnet(x_fast)
+                x_slow = self.slownet((x_slow, laterals))
             return torch.cat([x_slow, x_fast], dim=1)
 
     def show_CAM(self):

@@ -103,6 +103,7 @@ def from_channels_last(x: torch.Tensor, channels: int) -> torch.Tensor:
 # Batched packing for the composable models: pack_weights() remembers (descriptor, want_dgrad) per weight tensor; inside
 # ``prepacked(module)`` -- the models' forward() -- the operands of every remembered weight are packed up front by ONE batched
 # call (md_conv_pack_weights_batch: ~120 tiny launches per SlowFast step become 3) and pack_weights() hands them out.
+_pack_stream = [None]   # the stream the packs of the active prepacked() scope were made on
 _pack_memo = {}        # id(weight) -> (weak reference to the weight, descriptor fields, want_dgrad)
 _pack_ready = None     # inside prepacked(): id(weight) -> (descriptor fields, wf, wd)
 
@@ -148,6 +149,8 @@ class prepacked:
             ready[wid] = (key, wf, wd, wc)
         N.check(L.md_conv_pack_weights_batch(n, descs, wp, fp, dp, _stream()), "md_conv_pack_weights_batch")
         _pack_ready = ready
+        self.stream = torch.cuda.current_stream(items[0][1].device)
+        _pack_stream[0] = self.stream
         return self
 
     def __exit__(self, *exc):
@@ -162,6 +165,11 @@ def pack_weights(d: N.MdConvDesc, w: torch.Tensor, want_dgrad: bool = True):
     if _pack_ready is not None:
         hit = _pack_ready.get(id(w))
         if hit is not None and hit[0] == key and (hit[2] is not None or not want_dgrad):
+            cur = torch.cuda.current_stream(w.device)
+            if cur != _pack_stream[0]:                     # a branch on a side stream (src/utils/streams.py) reads packs made on another
+                hit[1].record_stream(cur)
+                if hit[2] is not None:
+                    hit[2].record_stream(cur)
             return hit[1], (hit[2] if want_dgrad else None)
     if isinstance(w, torch.nn.Parameter):                 # (views and temporaries have no stable identity)
         _pack_memo[id(w)] = (weakref.ref(w), key, bool(want_dgrad))

@@ -170,3 +170,43 @@ def test_train_per_epoch_drives_the_fused_model():
     assert len(changed) > 0.9 * len(before)
     vloss, vacc, vf1 = valid_per_epoch(loader, m, opt, gb, "cuda:0", "multi-GB")
     assert np.isfinite(vloss)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["cfg4", "cfg5"])
+def test_encoders_on_separate_streams_are_bit_identical_to_one_stream(tag):
+    """The 0D encoder beside the video encoder on a side stream (and, for cfg5, the fast pathway beside the slow one;
+    src/utils/streams.py) against the same step on one stream: outputs, every parameter gradient and the running statistics
+    agree bit for bit, three times in a row."""
+    from src.utils import streams
+    torch.manual_seed(9)
+    m = _native(tag).cuda().train()
+    xv = torch.randn(4, 3, 5, 24, 24, device="cuda") if tag == "cfg4" else torch.randn(4, 3, 8, 32, 32, device="cuda")
+    xt = torch.randn(4, 5, 6, device="cuda") if tag == "cfg4" else torch.randn(4, 8, 6, device="cuda")
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    old = streams._ENABLED
+
+    def run(flag):
+        streams._ENABLED = flag
+        m.load_state_dict(sd)
+        for p in m.parameters():
+            p.grad = None
+        torch.manual_seed(10)                      # the 0D Transformer's NoiseLayer draws from the CPU generator
+        outs = m(xv, xt)
+        sum(o.square().sum() for o in outs).backward()
+        torch.cuda.synchronize()
+        return ([o.detach().clone() for o in outs], {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None},
+                {k: v.clone() for k, v in m.state_dict().items() if "running" in k})
+    try:
+        ref = run(False)
+        for _ in range(3):
+            got = run(True)
+            for a, b in zip(got[0], ref[0]):
+                assert torch.equal(a, b)
+            assert got[1].keys() == ref[1].keys()
+            for k in ref[1]:
+                assert torch.equal(got[1][k], ref[1][k]), k
+            for k in ref[2]:
+                assert torch.equal(got[2][k], ref[2][k]), k
+    finally:
+        streams._ENABLED = old

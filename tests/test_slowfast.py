@@ -110,3 +110,39 @@ def test_channels_last_resident_stages_are_bit_identical_to_the_reference_layout
         assert torch.equal(res[True][1][k], res[False][1][k]), k
     for k in res[True][2]:
         assert torch.equal(res[True][2][k], res[False][2][k]), k
+
+
+@pytest.mark.gpu
+def test_pathways_on_separate_streams_are_bit_identical_to_one_stream():
+    """Fast pathway on a side stream, slow pathway waiting lateral by lateral (src/utils/streams.py), against the same step on one
+    stream: the kernels and the order of the accumulations per tensor do not change, so logits, every parameter gradient and the
+    running statistics agree bit for bit; repeated to give a missing stream dependency the chance to show."""
+    import src.models.slowfast as sfm
+    from src.utils import streams
+    torch.manual_seed(4)
+    m = sfm.SlowFast(input_shape=(3, 16, 64, 64), layers=[1, 2, 2, 1], alpha=4, tau_fast=1, num_classes=2).cuda().train()
+    x = torch.randn(2, 3, 16, 64, 64, device="cuda")
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    old = streams._ENABLED
+
+    def run(flag):
+        streams._ENABLED = flag
+        m.load_state_dict(sd)
+        for p in m.parameters():
+            p.grad = None
+        out = m(x)
+        out.square().sum().backward()
+        torch.cuda.synchronize()
+        return (out.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()},
+                {k: v.clone() for k, v in m.state_dict().items() if "running" in k})
+    try:
+        ref = run(False)
+        for _ in range(3):
+            got = run(True)
+            assert torch.equal(got[0], ref[0])
+            for k in ref[1]:
+                assert torch.equal(got[1][k], ref[1][k]), k
+            for k in ref[2]:
+                assert torch.equal(got[2][k], ref[2][k]), k
+    finally:
+        streams._ENABLED = old

@@ -9,7 +9,7 @@ def timeit(f, n=20):
     e0.record()
     for _ in range(n): f()
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / n * 1e3
-for name, rows, Cc in [('c1s out 72ch 64x64', 8*21*64*64, 72), ('c1t out 32ch 64x64', 8*21*64*64, 32), ('c3s out 144ch 32x32', 8*11*32*32, 144), ('stem mid 45ch', 8*21*64*64, 45)]:
+for name, rows, Cc in [('c1 out 64ch 64x64', 8*21*64*64, 64), ('c1s out 72ch 64x64', 8*21*64*64, 72), ('c1t out 32ch 64x64', 8*21*64*64, 32), ('c3s out 144ch 32x32', 8*11*32*32, 144), ('stem mid 45ch', 8*21*64*64, 45)]:
     Cp = ops.cpad(Cc)
     y = torch.randn(rows, Cp, device='cuda'); dA = torch.randn(rows, Cp, device='cuda')
     st = torch.rand(4, Cp, device='cuda') + 0.5

@@ -53,6 +53,54 @@ def _forward(model, data, device, model_type):
     return out, out_vis, out_ts
 
 
+# MD_GRAPH_STEP=1: forward + loss + backward of every full-size training batch replayed from one HIP graph
+# (src/utils/graphed.py; the composable models -- SlowFast, ViViT, the 0D encoders, the fusion models -- are launch-bound:
+# cfg5 16 ms eager, 7.1 ms replayed).  The optimizer step, the bookkeeping and odd-sized batches stay eager.
+_GRAPH_STEPS = os.environ.get("MD_GRAPH_STEP") == "1"
+
+
+def _loss_signature(loss_fn):
+    """Everything of the loss modules a captured step bakes in: numbers by value, tensors by address (a replay reads their
+    current contents)."""
+    sig = []
+    for mod in loss_fn.modules():
+        for k, v in sorted(vars(mod).items()):
+            if k.startswith("_") or k == "training" or k == "last_pred":
+                continue
+            if isinstance(v, (bool, int, float, str)) or v is None:
+                sig.append((k, v))
+            elif isinstance(v, torch.Tensor):
+                sig.append((k, v.data_ptr(), tuple(v.shape)))
+            elif isinstance(v, (list, tuple)) and all(isinstance(e, (bool, int, float)) for e in v):
+                sig.append((k, tuple(v)))
+        for k, v in list(mod._buffers.items()) + list(mod._parameters.items()):
+            if v is not None:
+                sig.append((k, v.data_ptr(), tuple(v.shape)))
+    return tuple(sig)
+
+
+def _graphed_step(model, loss_fn, inputs, tgt, model_type):
+    """The cached GraphedStep of (model, loss configuration, batch shapes), captured on first use; None when capture is not
+    possible (then the loop stays eager for good and says so once)."""
+    from .utils.graphed import GraphedStep
+    key = (model_type, getattr(model, "use_stream", None), tuple(tuple(t.shape) for t in inputs), tuple(tgt.shape), tgt.dtype,
+           id(loss_fn), _loss_signature(loss_fn))
+    slot = model.__dict__.get("_md_graphed")
+    if slot is not None and slot[0] == key:
+        return slot[1]
+    if slot is not None and slot[1] is None and slot[0][:2] == key[:2] and slot[0][5] == key[5]:
+        return None                                           # capture already failed for this model / loss pair
+    model.__dict__.pop("_md_graphed", None)                   # (frees the previous graph and its memory pool)
+    slot = None
+    try:
+        gs = GraphedStep(model, loss_fn, inputs, tgt, keep_buffers=True)
+    except RuntimeError as e:
+        print("train_per_epoch | MD_GRAPH_STEP: capture refused, training eagerly (%s)" % str(e).split("\n")[0][:200])
+        gs = None
+    model.__dict__["_md_graphed"] = (key, gs)
+    return gs
+
+
 def _pred_of(loss_fn, output):
     """argmax softmax(output) (src/train.py:70).  The fused loss kernel already produced it for `output`."""
     p = getattr(loss_fn, "last_pred", None)
@@ -81,19 +129,41 @@ def train_per_epoch(
     total_pred, total_label = [], []
     total_size = 0
 
+    graph_ok = _GRAPH_STEPS and torch.device(device).type == "cuda" and isinstance(loss_fn, torch.nn.Module)
+    full_shape = None            # graph mode: the shape of the first batch is the one that is captured
+    was_eager = True
     for batch_idx, (data, target) in enumerate(train_loader):
-        optimizer.zero_grad()
-        output, output_vis, output_ts = _forward(model, data, device, model_type)
         tgt = target.to(device)
-        if model_type == 'multi-GB':
-            loss = loss_fn(output, output_vis, output_ts, tgt)
+        gs = None
+        if graph_ok:
+            inputs = [data.to(device)] if model_type == "single" else [data['video'].to(device), data['0D'].to(device)]
+            shape = tuple(tuple(t.shape) for t in inputs)
+            if full_shape is None:
+                full_shape = shape
+            if shape == full_shape:
+                gs = _graphed_step(model, loss_fn, inputs, tgt, model_type)
+        if gs is not None:
+            if was_eager:
+                gs.bind()
+                was_eager = False
+            outs, loss = gs(inputs, tgt)
+            output = outs[0] if isinstance(outs, tuple) else outs
+            if not torch.isfinite(loss):                      # (the replay already ran the backward: only the update is skipped)
+                print("train_per_epoch | Warning : loss nan occurs at batch_idx : {}".format(batch_idx))
+                continue
         else:
-            loss = loss_fn(output, tgt)
+            was_eager = True
+            optimizer.zero_grad()
+            output, output_vis, output_ts = _forward(model, data, device, model_type)
+            if model_type == 'multi-GB':
+                loss = loss_fn(output, output_vis, output_ts, tgt)
+            else:
+                loss = loss_fn(output, tgt)
 
-        if not torch.isfinite(loss):
-            print("train_per_epoch | Warning : loss nan occurs at batch_idx : {}".format(batch_idx))
-            continue
-        loss.backward()
+            if not torch.isfinite(loss):
+                print("train_per_epoch | Warning : loss nan occurs at batch_idx : {}".format(batch_idx))
+                continue
+            loss.backward()
 
         if getattr(optimizer, "fused_clip", False):         # src.optim.ClipAdamW: clip + update in one pass
             optimizer.step(max_norm=max_norm_grad)
@@ -103,8 +173,10 @@ def train_per_epoch(
             optimizer.step()
 
         ld = loss.detach()
-        loss_sum = ld if loss_sum is None else loss_sum + ld
         pred = _pred_of(loss_fn, output.detach())
+        if gs is not None:                                    # static tensors of the graph: the next replay overwrites them
+            ld, pred = ld.clone(), pred.clone()
+        loss_sum = ld if loss_sum is None else loss_sum + ld
         c = pred.eq(tgt.view_as(pred)).sum()
         correct = c if correct is None else correct + c
         total_size += pred.size(0)

@@ -21,7 +21,11 @@ import torch
 
 class GraphedStep:
     def __init__(self, model: torch.nn.Module, loss_fn: Callable, example_inputs: Sequence[torch.Tensor], example_target: torch.Tensor,
-                 warmup: int = 3):
+                 warmup: int = 3, keep_buffers: bool = False):
+        """``keep_buffers``: put the model's buffers (BatchNorm running statistics and step counters) back to their values from
+        before the warm-up steps once the graph exists -- a training loop that captures on its first batch then sees exactly the
+        updates an eager loop would have made."""
+        saved_buffers = [b.detach().clone() for b in model.buffers()] if keep_buffers else None
         # NoiseLayers draw from the CPU generator: switched to one pinned staging buffer each, which the captured upload reads on
         # every replay and __call__ refills beforehand
         self.noise_layers = [mod for mod in model.modules() if type(mod).__name__ == "NoiseLayer"]
@@ -60,7 +64,29 @@ class GraphedStep:
         model.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.outputs, self.loss = self._eager()
+            out, loss = self._eager()
+        # static results, detached: the autograd graph of the captured step (and with it the parameters' AccumulateGrad nodes)
+        # is released here, so a later GraphedStep of the same model does not find it alive
+        self.outputs = tuple(o.detach() for o in out) if isinstance(out, tuple) else out.detach()
+        self.loss = loss.detach()
+        del out, loss
+        self.params = [p for p in model.parameters() if p.grad is not None]
+        self.grads = [p.grad for p in self.params]
+        # tensors the loss modules publish as attributes (FocalLoss.last_pred ...): the replay rewrites these very tensors
+        self.published = [(mod, k, v) for mod in (loss_fn.modules() if isinstance(loss_fn, torch.nn.Module) else ())
+                          for k, v in vars(mod).items() if isinstance(v, torch.Tensor) and v.is_cuda and not k.startswith("_")]
+        if keep_buffers:
+            with torch.no_grad():
+                for b, v in zip(model.buffers(), saved_buffers):
+                    b.copy_(v)
+
+    def bind(self):
+        """Point every parameter's ``.grad`` (and the loss modules' published tensors) at the static tensors the graph writes --
+        needed after an eager step of the same model replaced them (``optimizer.zero_grad()`` + ``backward``)."""
+        for p, g in zip(self.params, self.grads):
+            p.grad = g
+        for mod, k, v in self.published:
+            setattr(mod, k, v)
 
     def _eager(self):
         out = self.model(*self.inputs)
@@ -82,4 +108,6 @@ class GraphedStep:
         self.graph.replay()
         if self.noise_layers:
             self._done.record()
+        for mod, k, v in self.published:                   # (an eager validation pass in between re-pointed them)
+            setattr(mod, k, v)
         return self.outputs, self.loss

@@ -58,3 +58,62 @@ def test_stale_autograd_graph_is_refused_not_crashed():
     del loss
     gs = GraphedStep(m, loss_fn, [x], y)                 # and after dropping it the same model captures fine
     gs([x], y); torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_train_per_epoch_with_graph_replay_matches_the_eager_loop():
+    """MD_GRAPH_STEP=1 (src/train.py): every full-size batch of train_per_epoch is one graph replay, the odd-sized last batch and
+    the optimizer stay eager.  Two epochs over the same data from the same initial state (SlowFast + MLSTM_FCN, no dropout,
+    GradientBlending over LDAM, ClipAdamW): the same kernels on the same bytes, so losses, accuracies, parameters and BatchNorm
+    statistics agree bit for bit with the eager loop."""
+    from torch.utils.data import DataLoader, Dataset
+    import src.train as tr
+    from src.GradientBlending import GradientBlending
+    from src.loss import LDAMLoss
+    from src.models.fusion import FusionGB
+    from src.models.MLSTM_FCN import MLSTM_FCN
+    from src.models.slowfast import SlowFast
+    from src.optim import ClipAdamW
+
+    class Pairs(Dataset):
+        def __init__(self):
+            g = torch.Generator().manual_seed(5)
+            self.v = torch.randn(10, 3, 8, 32, 32, generator=g); self.t = torch.randn(10, 8, 6, generator=g)
+            self.y = torch.tensor([0, 1, 0, 1, 1, 0, 0, 1, 1, 0])
+
+        def __len__(self):
+            return 10
+
+        def __getitem__(self, i):
+            return {"video": self.v[i], "0D": self.t[i]}, self.y[i]
+
+    def make():
+        torch.manual_seed(6)
+        vis = SlowFast(input_shape=(3, 8, 32, 32), layers=[1, 1, 1, 1], alpha=4, tau_fast=1, num_classes=2, alpha_elu=1.0)
+        ts = MLSTM_FCN(n_features=6, fcn_dim=8, kernel_size=3, stride=1, seq_len=8, lstm_dim=8, lstm_n_layers=1, lstm_bidirectional=True,
+                       lstm_dropout=0.0, reduction=4, alpha=0.01, n_classes=2)
+        ts.noise.std = 0.0      # (the NoiseLayer draws from the CPU generator: the capture's warm-up steps would shift its sequence)
+        return FusionGB(2, vis, ts).cuda()
+
+    def run(graph):
+        old = tr._GRAPH_STEPS
+        tr._GRAPH_STEPS = graph
+        try:
+            m = make()
+            ld = LDAMLoss([100, 2000], max_m=0.5, weight=torch.tensor([1.0, 1.0]).cuda(), s=1.0)
+            gb = GradientBlending(ld, ld, ld, 0.1, 0.4, 0.5)
+            opt = ClipAdamW(m.parameters(), lr=1e-3, max_norm=1.0)
+            loader = DataLoader(Pairs(), batch_size=4, shuffle=False)          # batches of 4, 4, 2
+            hist = [tr.train_per_epoch(loader, m, opt, None, gb, "cuda:0", 1.0, "multi-GB") for _ in range(2)]
+            used = m.__dict__.get("_md_graphed")
+            m.__dict__.pop("_md_graphed", None)
+            return hist, {k: v.detach().clone() for k, v in m.state_dict().items()}, used
+        finally:
+            tr._GRAPH_STEPS = old
+
+    h0, sd0, used0 = run(False)
+    h1, sd1, used1 = run(True)
+    assert used0 is None and used1 is not None and used1[1] is not None          # the graph was really captured and used
+    assert h0 == h1
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k

@@ -1676,7 +1676,8 @@ int linear_split_launch(int f16, const float* A, int M, int K, const float* W, i
   static const int off = getenv("MD_LINEAR_SPLIT") && atoi(getenv("MD_LINEAR_SPLIT")) == 0;
   if (off || (K & 3) || (Kp % LB_K) || (N16 & 15)) return MD_ERR_UNSUPPORTED;
   int npb = 128;
-  while (md_cdiv(M, LB_M) * md_cdiv(N16, npb) < 512 && npb > 32) npb >>= 1;
+  static const int fill = getenv("MD_LINEAR_FILL") ? atoi(getenv("MD_LINEAR_FILL")) : 512;
+  while (md_cdiv(M, LB_M) * md_cdiv(N16, npb) < fill && npb > 32) npb >>= 1;
   const dim3 grid(md_cdiv(M, LB_M), md_cdiv(N16, npb));
   if (f16) MD_KLAUNCH(k_linear_split<true>, grid, dim3(256), 0, s, A, M, K, W, Kp, N16, C, ldc, accumulate, npb);
   else MD_KLAUNCH(k_linear_split<false>, grid, dim3(256), 0, s, A, M, K, W, Kp, N16, C, ldc, accumulate, npb);

@@ -35,7 +35,13 @@ class NoiseLayer(nn.Module):
         if not self.training:
             return x
         ops.require_cuda(x)
-        noise = self._draw_static(x) if self.__dict__.get("_graph_mode") else self._draw(x)
+        static = self.__dict__.get("_graph_mode")
+        if static and not torch.cuda.is_current_stream_capturing():
+            # an eager step of another batch size beside a captured one (the short last batch of an epoch): the staging buffer the
+            # graph uploads from must stay as it is
+            st = self.__dict__.get("_static")
+            static = st is None or st[0].shape == x.shape
+        noise = self._draw_static(x) if static else self._draw(x)
         return _AddNoise.apply(ops.f32(x), noise, self.mean, self.std)
 
     # -- whole-step HIP graphs (src/utils/graphed.py): the upload must read the SAME pinned buffer on every replay, and the host

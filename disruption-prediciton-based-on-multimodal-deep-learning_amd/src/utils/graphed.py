@@ -31,6 +31,7 @@ class GraphedStep:
         self.noise_layers = [mod for mod in model.modules() if type(mod).__name__ == "NoiseLayer"]
         for mod in self.noise_layers:
             mod.__dict__["_graph_mode"] = True
+            mod.__dict__.pop("_static", None)              # (one live GraphedStep per model: a new one brings its own staging buffer)
         self.model, self.loss_fn = model, loss_fn
         self._done = torch.cuda.Event()
         self.inputs = [t.detach().clone() for t in example_inputs]
@@ -62,6 +63,8 @@ class GraphedStep:
         for w in caught:                                   # anything else: pass on
             warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
         model.zero_grad(set_to_none=True)
+        loss_mods = list(loss_fn.modules()) if isinstance(loss_fn, torch.nn.Module) else []
+        before = {(id(mod), k): v for mod in loss_mods for k, v in vars(mod).items() if isinstance(v, torch.Tensor)}   # (held: no id reuse)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             out, loss = self._eager()
@@ -73,8 +76,9 @@ class GraphedStep:
         self.params = [p for p in model.parameters() if p.grad is not None]
         self.grads = [p.grad for p in self.params]
         # tensors the loss modules publish as attributes (FocalLoss.last_pred ...): the replay rewrites these very tensors
-        self.published = [(mod, k, v) for mod in (loss_fn.modules() if isinstance(loss_fn, torch.nn.Module) else ())
-                          for k, v in vars(mod).items() if isinstance(v, torch.Tensor) and v.is_cuda and not k.startswith("_")]
+        self.published = [(mod, k, v) for mod in loss_mods for k, v in vars(mod).items()
+                          if isinstance(v, torch.Tensor) and v.is_cuda and before.get((id(mod), k)) is not v]
+        del before
         if keep_buffers:
             with torch.no_grad():
                 for b, v in zip(model.buffers(), saved_buffers):

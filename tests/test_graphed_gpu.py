@@ -117,3 +117,42 @@ def test_train_per_epoch_with_graph_replay_matches_the_eager_loop():
     assert h0 == h1
     for k in sd0:
         assert torch.equal(sd0[k], sd1[k]), k
+
+
+@pytest.mark.gpu
+def test_eager_step_of_another_batch_size_leaves_the_captured_noise_buffer_alone():
+    """The NoiseLayer of a captured 0D encoder uploads from one pinned staging buffer that GraphedStep refills before each replay.
+    An eager step with a different batch size in between (the short last batch of an epoch in the MD_GRAPH_STEP loop) must not
+    replace that buffer: afterwards a replay still equals the eager step that draws the same CPU-generator noise."""
+    from src.loss import FocalLoss
+    from src.models.MLSTM_FCN import MLSTM_FCN
+    from src.utils.graphed import GraphedStep
+    torch.manual_seed(11)
+    m = MLSTM_FCN(n_features=6, fcn_dim=8, kernel_size=3, stride=1, seq_len=8, lstm_dim=8, lstm_n_layers=1, lstm_bidirectional=True,
+                  lstm_dropout=0.0, reduction=4, alpha=0.01, n_classes=2).cuda().train()
+    m.noise.std = 0.5                                            # make the noise matter
+    loss_fn = FocalLoss(torch.tensor([1.0, 1.0]).cuda(), 2.0)
+    x = torch.randn(4, 8, 6, device="cuda"); y = torch.tensor([0, 1, 1, 0], device="cuda")
+    gs = GraphedStep(m, loss_fn, [x], y)
+    static = m.noise.__dict__["_static"]
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                                # an eager step with two samples
+        m.zero_grad(set_to_none=True)
+        loss_fn(m(x[:2]), y[:2]).backward()
+    side.synchronize()
+    assert m.noise.__dict__["_static"] is static
+    gs.bind()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    torch.manual_seed(12)
+    _, loss_g = gs([x], y)
+    loss_g = float(loss_g); grads_g = {k: p.grad.clone() for k, p in m.named_parameters()}
+    m.load_state_dict(sd)
+    torch.manual_seed(12)
+    with torch.cuda.stream(side):
+        m.zero_grad(set_to_none=True)
+        loss_e = loss_fn(m(x), y); loss_e.backward()
+    side.synchronize()
+    assert float(loss_e.detach()) == loss_g
+    for k, p in m.named_parameters():
+        assert torch.equal(p.grad, grads_g[k]), k
+    del loss_e

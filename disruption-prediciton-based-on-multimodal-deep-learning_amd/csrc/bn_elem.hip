@@ -598,6 +598,57 @@ extern "C" int md_cl_to_nchw(const float* x, int32_t B, int32_t C, int64_t thw, 
   return MD_OK;
 }
 
+// Channel concatenation of two channels-last tensors (SlowFast's lateral connection, slowfast.py:26-40: torch.cat([slow, lateral],
+// dim=1)): out[row][0..Ca) = a[row][0..Ca), out[row][Ca..Ca+Cb) = b[row][0..Cb), padding channels zero.  One thread per output
+// channel quad of a row; the backward splits the gradient the same way (padding channels of da / db zero).
+__global__ __launch_bounds__(256) void k_cat_cl(const float* __restrict__ a, int Ca, int Cpa, const float* __restrict__ b, int Cb,
+                                                int Cpb, int Cpo, int64_t total, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int q = Cpo >> 2;
+  const int64_t row = i / q; const int c0 = (int)(i - row * q) * 4;
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = c0 + e;
+    v[e] = c < Ca ? a[row * Cpa + c] : (c < Ca + Cb ? b[row * Cpb + (c - Ca)] : 0.f);
+  }
+  *(float4*)(out + row * Cpo + c0) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__global__ __launch_bounds__(256) void k_split_cl(const float* __restrict__ g, int Cpo, int Ca, int Cpa, int Cb, int Cpb, int64_t total,
+                                                  float* __restrict__ da, float* __restrict__ db) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int qa = Cpa >> 2, q = qa + (Cpb >> 2);
+  const int64_t row = i / q; const int k = (int)(i - row * q);
+  const bool isa = k < qa;
+  const int c0 = (isa ? k : k - qa) * 4, n = isa ? Ca : Cb, off = isa ? 0 : Ca;
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = c0 + e < n ? g[row * Cpo + off + c0 + e] : 0.f;
+  *(float4*)((isa ? da + row * Cpa : db + row * Cpb) + c0) = make_float4(v[0], v[1], v[2], v[3]);
+}
+extern "C" int md_cat_cl(const float* a, int32_t Ca, const float* b, int32_t Cb, int64_t rows, float* out, void* stream) {
+  if (!a || !b || !out) return MD_ERR_NULL;
+  if (Ca <= 0 || Cb <= 0 || rows <= 0) return MD_ERR_BAD_SHAPE;
+  const int Cpo = md_cpad(Ca + Cb);
+  const int64_t total = rows * (Cpo / 4);
+  MD_KLAUNCH(k_cat_cl, dim3((unsigned)md_cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, a, Ca, md_cpad(Ca), b, Cb, md_cpad(Cb),
+             Cpo, total, out);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+extern "C" int md_split_cl(const float* g, int32_t Ca, int32_t Cb, int64_t rows, float* da, float* db, void* stream) {
+  if (!g || !da || !db) return MD_ERR_NULL;
+  if (Ca <= 0 || Cb <= 0 || rows <= 0) return MD_ERR_BAD_SHAPE;
+  const int Cpa = md_cpad(Ca), Cpb = md_cpad(Cb);
+  const int64_t total = rows * ((Cpa + Cpb) / 4);
+  MD_KLAUNCH(k_split_cl, dim3((unsigned)md_cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, g, md_cpad(Ca + Cb), Ca, Cpa, Cb, Cpb,
+             total, da, db);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+
 extern "C" int md_avgpool_fwd(const float* x, int32_t B, int32_t C, int64_t thw, float* feat, void* stream) {
   if (!x || !feat) return MD_ERR_NULL;
   int rc = check_rows(thw, C); if (rc) return rc;

@@ -69,6 +69,8 @@ SIGNATURES = {
     "md_bn_act_split": (C.c_int, [_VIEW, _I64, _I32, _P, _P]),
     "md_nchw_to_cl": (C.c_int, [_P, _I32, _I32, _I64, _P, _P]),
     "md_cl_to_nchw": (C.c_int, [_P, _I32, _I32, _I64, _P, _P]),
+    "md_cat_cl": (C.c_int, [_P, _I32, _P, _I32, _I64, _P, _P]),
+    "md_split_cl": (C.c_int, [_P, _I32, _I32, _I64, _P, _P, _P]),
     "md_avgpool_fwd": (C.c_int, [_P, _I32, _I32, _I64, _P, _P]),
     "md_avgpool_bwd": (C.c_int, [_P, _I32, _I32, _I64, _P, _P]),
     "md_head_save_floats": (_SZ, [_I32, _I32, _I32]),

@@ -152,14 +152,33 @@ def from_cl_act(a: CLAct) -> torch.Tensor:
     return _FromCLFunction.apply(a.t, a.C)
 
 
+class _CatCLFunction(torch.autograd.Function):
+    """torch.cat on the channel axis of two channels-last activations, one launch each way (md_cat_cl / md_split_cl)."""
+
+    @staticmethod
+    def forward(ctx, a, Ca, b, Cb):
+        a = ops.f32(a).contiguous(); b = ops.f32(b).contiguous()
+        ops.require_cuda(a, b)
+        assert a.shape[:-1] == b.shape[:-1] and a.shape[-1] == ops.cpad(Ca) and b.shape[-1] == ops.cpad(Cb)
+        rows = a.numel() // a.shape[-1]
+        out = torch.empty(a.shape[:-1] + (ops.cpad(Ca + Cb),), device=a.device, dtype=torch.float32)
+        N.check(N.lib().md_cat_cl(ops._p(a), int(Ca), ops._p(b), int(Cb), rows, ops._p(out), ops._stream()), "md_cat_cl")
+        ctx.Ca, ctx.Cb, ctx.sa, ctx.sb = int(Ca), int(Cb), a.shape, b.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = ops.f32(g).contiguous()
+        da = torch.empty(ctx.sa, device=g.device, dtype=torch.float32)
+        db = torch.empty(ctx.sb, device=g.device, dtype=torch.float32)
+        rows = da.numel() // da.shape[-1]
+        N.check(N.lib().md_split_cl(ops._p(g), ctx.Ca, ctx.Cb, rows, ops._p(da), ops._p(db), ops._stream()), "md_split_cl")
+        return da, None, db, None
+
+
 def cat_cl(a: CLAct, b: CLAct) -> CLAct:
-    """torch.cat([a, b], dim=1) of the logical tensors, in the channels-last layout (padding re-established at the end)."""
-    Cc = a.C + b.C
-    t = torch.cat((a.t[..., :a.C], b.t[..., :b.C]), dim=-1)
-    pad = ops.cpad(Cc) - Cc
-    if pad:
-        t = torch.nn.functional.pad(t, (0, pad))
-    return CLAct(t.contiguous(), Cc)
+    """torch.cat([a, b], dim=1) of the logical tensors, in the channels-last layout (padding channels zero)."""
+    return CLAct(_CatCLFunction.apply(a.t, a.C, b.t, b.C), a.C + b.C)
 
 
 def conv_bn_leaky(x, conv: torch.nn.Conv3d, bn: torch.nn.BatchNorm3d, slope: float, training: bool):

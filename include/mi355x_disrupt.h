@@ -197,6 +197,12 @@ int md_conv_wgrad_fmt2(const MdConvDesc* d, const MdActView* x, int x_split, con
 int md_nchw_to_cl(const float* x, int32_t B, int32_t C, int64_t thw, float* out, void* stream);
 int md_cl_to_nchw(const float* x, int32_t B, int32_t C, int64_t thw, float* out, void* stream);
 
+/* torch.cat([a, b], dim=1) of two channels-last tensors with `rows` pixels each (the lateral connection of SlowFast,
+ * src/models/slowfast.py:26-40): out has pitch md_cpad(Ca + Cb), padding channels zero.  md_split_cl is its backward: the
+ * gradient g (pitch md_cpad(Ca + Cb)) split into da (pitch md_cpad(Ca)) and db (pitch md_cpad(Cb)), padding channels zero. */
+int md_cat_cl(const float* a, int32_t Ca, const float* b, int32_t Cb, int64_t rows, float* out, void* stream);
+int md_split_cl(const float* g, int32_t Ca, int32_t Cb, int64_t rows, float* da, float* db, void* stream);
+
 /* AdaptiveAvgPool3d(1) + view (R2Plus1D.py:215,224-225): feat[B][C] = mean over thw of x[B][thw][Cp]. */
 int md_avgpool_fwd(const float* x, int32_t B, int32_t C, int64_t thw, float* feat, void* stream);
 int md_avgpool_bwd(const float* dfeat, int32_t B, int32_t C, int64_t thw, float* dx, void* stream);

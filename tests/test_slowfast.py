@@ -146,3 +146,29 @@ def test_pathways_on_separate_streams_are_bit_identical_to_one_stream():
                 assert torch.equal(got[2][k], ref[2][k]), k
     finally:
         streams._ENABLED = old
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Ca,Cb", [(64, 16), (5, 3), (30, 9), (8, 8)])
+def test_channels_last_concatenation_matches_torch_cat(Ca, Cb):
+    """md_cat_cl / md_split_cl (the lateral connection, slowfast.py:26-40) against torch.cat on the logical (B,C,T,H,W) tensors:
+    values and both gradients bit-exact, padding channels exactly zero."""
+    from src import ops
+    from src.models._unit import CLAct, cat_cl
+    g = torch.Generator().manual_seed(Ca * 100 + Cb)
+    a = torch.randn(2, Ca, 3, 5, 4, generator=g).cuda().requires_grad_(True)
+    b = torch.randn(2, Cb, 3, 5, 4, generator=g).cuda().requires_grad_(True)
+    acl = ops.to_channels_last(a.detach()).requires_grad_(True)
+    bcl = ops.to_channels_last(b.detach()).requires_grad_(True)
+    out = cat_cl(CLAct(acl, Ca), CLAct(bcl, Cb))
+    ref = torch.cat([a, b], dim=1)
+    assert out.C == Ca + Cb and out.t.shape[-1] == ops.cpad(Ca + Cb)
+    assert torch.equal(ops.from_channels_last(out.t.detach(), Ca + Cb), ref.detach())
+    assert float(out.t.detach()[..., Ca + Cb:].abs().sum()) == 0.0
+    w = torch.randn(ref.shape, generator=g).cuda()
+    (ref * w).sum().backward()
+    wcl = ops.to_channels_last(w)
+    (out.t * wcl).sum().backward()
+    assert torch.equal(ops.from_channels_last(acl.grad, Ca), a.grad)
+    assert torch.equal(ops.from_channels_last(bcl.grad, Cb), b.grad)
+    assert float(acl.grad[..., Ca:].abs().sum()) == 0.0 and float(bcl.grad[..., Cb:].abs().sum()) == 0.0

@@ -3,6 +3,7 @@
 // forms the reference uses.  Sequences are tiny (S = 21 tokens, d_model 128-256, head dim 16-32): one workgroup per row /
 // per (batch, head); everything fixed-order fp32.
 #include "common.h"
+#include "patch_common.h"
 #include <map>
 #include <mutex>
 
@@ -239,6 +240,28 @@ __device__ __forceinline__ void at_stage(float* tile, cfp base, int width, int r
     *(float4*)(tile + r * P + c * 4) = v;
   }
 }
+// the same staging in two halves, so that the global loads of the next 64 rows are in flight while the current tile is used
+template <int DH> struct AtRegs { float4 v[64 * (DH / 4) / 256]; };
+template <int DH>
+__device__ __forceinline__ void at_fetch(AtRegs<DH>& rg, cfp base, int width, int r0, int S, int B, int b, int bf) {
+  constexpr int CH = DH / 4;
+#pragma unroll
+  for (int k = 0; k < 64 * CH / 256; ++k) {
+    const int e = threadIdx.x + 256 * k, r = e / CH, c = e - r * CH, i = r0 + r;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < S) v = *(const float4*)(base + (bf ? (size_t)b * S + i : (size_t)i * B + b) * width + c * 4);
+    rg.v[k] = v;
+  }
+}
+template <int DH, int P>
+__device__ __forceinline__ void at_commit(float* tile, const AtRegs<DH>& rg) {
+  constexpr int CH = DH / 4;
+#pragma unroll
+  for (int k = 0; k < 64 * CH / 256; ++k) {
+    const int e = threadIdx.x + 256 * k, r = e / CH, c = e - r * CH;
+    *(float4*)(tile + r * P + c * 4) = rg.v[k];
+  }
+}
 // acc[t] (t < nt) = afrag (16 x DH) . rows^T for the rows of `base` (staged 64 at a time)
 template <int DH>
 __device__ __forceinline__ void at_scores(f32x4 (&acc)[AT_MAXT], const f32x4 (&a)[DH / 16], float* tile, cfp base, int width, int S,
@@ -287,6 +310,83 @@ __device__ __forceinline__ void at_apply(f32x4 (&o)[DH / 16], const float* pw, i
     }
   }
 }
+// ---- split-precision form of the two products (every fp32 product as three 16-bit MFMAs on hi + lo halves, exactly as in the
+// convolution kernels: fp16 halves in the forward pass, bf16 in the backward pass; v_mfma_f32_16x16x32: 5.3x the rate of the fp32
+// instruction for the same contraction).  The LDS tiles stay fp32; a lane reads the 8 values it feeds to one instruction (k = 8 lg
+// .. 8 lg + 7 of a 32-wide k block, the same permutation on both sides) and splits them in registers.
+template <bool F16>
+__device__ __forceinline__ void at_split8(const float* v, uint4& h, uint4& l) {
+  if (F16) split8_f16(v, h, l); else split8(v, h, l);
+}
+template <bool F16>
+__device__ __forceinline__ f32x4 at_mma3(uint4 ah, uint4 al, uint4 bh, uint4 bl, f32x4 c) {
+  c = mma<F16>(ah, bh, c);
+  c = mma<F16>(ah, bl, c);
+  return mma<F16>(al, bh, c);
+}
+// acc[t] (t < nt) = afrag (16 x DH, pre-split per 32-wide k block) . rows^T
+template <int DH, bool F16>
+__device__ __forceinline__ void at_scores_sp(f32x4 (&acc)[AT_MAXT], const uint4 (&ah)[DH / 32], const uint4 (&al)[DH / 32], float* tile,
+                                             cfp base, int width, int S, int B, int b, int bf, int nt, int li, int lg) {
+  AtRegs<DH> rg;
+  at_fetch<DH>(rg, base, width, 0, S, B, b, bf);
+#pragma unroll
+  for (int kt = 0; kt < AT_MAXT / 4; ++kt) {
+    if (kt * 4 < nt) {
+      __syncthreads();
+      at_commit<DH, AT_KP>(tile, rg);
+      __syncthreads();
+      if ((kt + 1) * 4 < nt) at_fetch<DH>(rg, base, width, (kt + 1) * 64, S, B, b, bf);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (kt * 4 + j < nt) {
+#pragma unroll
+          for (int s = 0; s < DH / 32; ++s) {
+            const float* p = tile + (16 * j + li) * AT_KP + s * 32 + lg * 8;
+            float v[8];
+            *(float4*)v = *(const float4*)p; *(float4*)(v + 4) = *(const float4*)(p + 4);
+            uint4 bh, bl;
+            at_split8<F16>(v, bh, bl);
+            acc[kt * 4 + j] = at_mma3<F16>(ah[s], al[s], bh, bl, acc[kt * 4 + j]);
+          }
+        }
+      }
+    }
+  }
+}
+// o (16 x DH) = Pw (16 x 32*ceil(nt/2), per-wave LDS buffer, pitch pp, columns past the last tile zero) . rows of `base`
+// (`rg`: rows 0..63 of `base`, fetched by the caller -- before its softmax / dS arithmetic, which hides that latency)
+template <int DH, bool F16>
+__device__ __forceinline__ void at_apply_sp(f32x4 (&o)[DH / 16], const float* pw, int pp, float* tile, AtRegs<DH>& rg, cfp base, int width,
+                                            int S, int B, int b, int bf, int nt, int li, int lg) {
+#pragma unroll
+  for (int jn = 0; jn < DH / 16; ++jn) o[jn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int kt = 0; kt * 4 < nt; ++kt) {
+    __syncthreads();
+    at_commit<DH, AT_VP>(tile, rg);
+    __syncthreads();
+    if ((kt + 1) * 4 < nt) at_fetch<DH>(rg, base, width, (kt + 1) * 64, S, B, b, bf);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      if (kt * 4 + kb * 2 < nt) {
+        const float* pa = pw + li * pp + kt * 64 + kb * 32 + lg * 8;
+        float v[8];
+        *(float4*)v = *(const float4*)pa; *(float4*)(v + 4) = *(const float4*)(pa + 4);
+        uint4 ph, pl;
+        at_split8<F16>(v, ph, pl);
+#pragma unroll
+        for (int jn = 0; jn < DH / 16; ++jn) {
+          float w[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w[e] = tile[(kb * 32 + lg * 8 + e) * AT_VP + jn * 16 + li];
+          uint4 vh, vl;
+          at_split8<F16>(w, vh, vl);
+          o[jn] = at_mma3<F16>(ph, pl, vh, vl, o[jn]);
+        }
+      }
+    }
+  }
+}
 __device__ __forceinline__ float at_group_max(float v) {
 #pragma unroll
   for (int o = 8; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
@@ -298,7 +398,7 @@ __device__ __forceinline__ float at_group_sum(float v) {
   return v;
 }
 
-template <int DH>
+template <int DH, bool SP = false>
 __global__ __launch_bounds__(256) void k_attn_mfma_fwd(cfp qkv, int S, int B, int D, int H, int bf, float scale, int pp,
                                                       float* __restrict__ probs, float* __restrict__ out) {
   extern __shared__ float sm[];
@@ -307,8 +407,28 @@ __global__ __launch_bounds__(256) void k_attn_mfma_fwd(cfp qkv, int S, int B, in
   float* pw = sm + 64 * AT_KP + wave * 16 * pp;      // per-wave 16 x pp
   const int bh = blockIdx.x, b = bh / H, h = bh - b * H, nt = (S + 15) >> 4;
   const int q0 = blockIdx.y * 64 + wave * 16;
-  f32x4 a[DH / 16];
-  {
+  f32x4 acc[AT_MAXT];
+#pragma unroll
+  for (int t = 0; t < AT_MAXT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  AtRegs<DH> vpre;                                   // (split form) first 64 rows of the second product's staged operand
+  if constexpr (SP) {
+    uint4 ah[DH / 32], al[DH / 32];
+    const int i = q0 + li;
+#pragma unroll
+    for (int s = 0; s < DH / 32; ++s) {
+      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (i < S) {
+        const float* p = qkv + (bf ? (size_t)b * S + i : (size_t)i * B + b) * 3 * D + h * DH + s * 32 + lg * 8;
+        *(float4*)v = *(const float4*)p; *(float4*)(v + 4) = *(const float4*)(p + 4);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= scale;
+      at_split8<true>(v, ah[s], al[s]);
+    }
+    at_scores_sp<DH, true>(acc, ah, al, tile, qkv + D + h * DH, 3 * D, S, B, b, bf, nt, li, lg);
+    at_fetch<DH>(vpre, qkv + 2 * D + h * DH, 3 * D, 0, S, B, b, bf);
+  } else {
+    f32x4 a[DH / 16];
     const int i = q0 + li;
 #pragma unroll
     for (int s = 0; s < DH / 16; ++s) {
@@ -316,11 +436,8 @@ __global__ __launch_bounds__(256) void k_attn_mfma_fwd(cfp qkv, int S, int B, in
       if (i < S) v = *(const f32x4*)(qkv + (bf ? (size_t)b * S + i : (size_t)i * B + b) * 3 * D + h * DH + (s * 4 + lg) * 4);
       a[s] = v * scale;
     }
+    at_scores<DH>(acc, a, tile, qkv + D + h * DH, 3 * D, S, B, b, bf, nt, li, lg);
   }
-  f32x4 acc[AT_MAXT];
-#pragma unroll
-  for (int t = 0; t < AT_MAXT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  at_scores<DH>(acc, a, tile, qkv + D + h * DH, 3 * D, S, B, b, bf, nt, li, lg);
   // softmax over the key axis (columns 16 t + li), one row per (lg, r)
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -345,7 +462,15 @@ __global__ __launch_bounds__(256) void k_attn_mfma_fwd(cfp qkv, int S, int B, in
     }
   }
   f32x4 o[DH / 16];
-  at_apply<DH>(o, pw, pp, tile, qkv + 2 * D + h * DH, 3 * D, S, B, b, bf, nt, li, lg);
+  if constexpr (SP) {
+    if (nt & 1) {                                     // the second half of the last 32-key block
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pw[(4 * lg + r) * pp + 16 * nt + li] = 0.f;
+    }
+    at_apply_sp<DH, true>(o, pw, pp, tile, vpre, qkv + 2 * D + h * DH, 3 * D, S, B, b, bf, nt, li, lg);
+  } else {
+    at_apply<DH>(o, pw, pp, tile, qkv + 2 * D + h * DH, 3 * D, S, B, b, bf, nt, li, lg);
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = q0 + 4 * lg + r;
@@ -358,7 +483,7 @@ __global__ __launch_bounds__(256) void k_attn_mfma_fwd(cfp qkv, int S, int B, in
 }
 
 // pass A: dP = dO V^T; dS = P (dP - rowsum(dP P)) scale -> ds_out; dq = dS K
-template <int DH>
+template <int DH, bool SP = false>
 __global__ __launch_bounds__(256) void k_attn_mfma_bwd_q(cfp qkv, cfp probs, cfp dout, int S, int B, int D, int H, int bf, float scale,
                                                         int pp, float* __restrict__ ds_out, float* __restrict__ dqkv) {
   extern __shared__ float sm[];
@@ -367,8 +492,26 @@ __global__ __launch_bounds__(256) void k_attn_mfma_bwd_q(cfp qkv, cfp probs, cfp
   float* pw = sm + 64 * AT_KP + wave * 16 * pp;
   const int bh = blockIdx.x, b = bh / H, h = bh - b * H, nt = (S + 15) >> 4;
   const int q0 = blockIdx.y * 64 + wave * 16;
-  f32x4 a[DH / 16];
-  {
+  f32x4 acc[AT_MAXT];
+#pragma unroll
+  for (int t = 0; t < AT_MAXT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  AtRegs<DH> vpre;
+  if constexpr (SP) {
+    uint4 ah[DH / 32], al[DH / 32];
+    const int i = q0 + li;
+#pragma unroll
+    for (int s = 0; s < DH / 32; ++s) {
+      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (i < S) {
+        const float* p = dout + (bf ? (size_t)b * S + i : (size_t)i * B + b) * D + h * DH + s * 32 + lg * 8;
+        *(float4*)v = *(const float4*)p; *(float4*)(v + 4) = *(const float4*)(p + 4);
+      }
+      at_split8<false>(v, ah[s], al[s]);
+    }
+    at_scores_sp<DH, false>(acc, ah, al, tile, qkv + 2 * D + h * DH, 3 * D, S, B, b, bf, nt, li, lg);
+    at_fetch<DH>(vpre, qkv + D + h * DH, 3 * D, 0, S, B, b, bf);
+  } else {
+    f32x4 a[DH / 16];
     const int i = q0 + li;
 #pragma unroll
     for (int s = 0; s < DH / 16; ++s) {
@@ -376,11 +519,8 @@ __global__ __launch_bounds__(256) void k_attn_mfma_bwd_q(cfp qkv, cfp probs, cfp
       if (i < S) v = *(const f32x4*)(dout + (bf ? (size_t)b * S + i : (size_t)i * B + b) * D + h * DH + (s * 4 + lg) * 4);
       a[s] = v;
     }
+    at_scores<DH>(acc, a, tile, qkv + 2 * D + h * DH, 3 * D, S, B, b, bf, nt, li, lg);
   }
-  f32x4 acc[AT_MAXT];
-#pragma unroll
-  for (int t = 0; t < AT_MAXT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  at_scores<DH>(acc, a, tile, qkv + 2 * D + h * DH, 3 * D, S, B, b, bf, nt, li, lg);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = q0 + 4 * lg + r;
@@ -405,7 +545,15 @@ __global__ __launch_bounds__(256) void k_attn_mfma_bwd_q(cfp qkv, cfp probs, cfp
     }
   }
   f32x4 o[DH / 16];
-  at_apply<DH>(o, pw, pp, tile, qkv + D + h * DH, 3 * D, S, B, b, bf, nt, li, lg);
+  if constexpr (SP) {
+    if (nt & 1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pw[(4 * lg + r) * pp + 16 * nt + li] = 0.f;
+    }
+    at_apply_sp<DH, false>(o, pw, pp, tile, vpre, qkv + D + h * DH, 3 * D, S, B, b, bf, nt, li, lg);
+  } else {
+    at_apply<DH>(o, pw, pp, tile, qkv + D + h * DH, 3 * D, S, B, b, bf, nt, li, lg);
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = q0 + 4 * lg + r;
@@ -417,7 +565,7 @@ __global__ __launch_bounds__(256) void k_attn_mfma_bwd_q(cfp qkv, cfp probs, cfp
   }
 }
 // pass B (per 16 keys j): dk[j] = sum_i dS[i][j] q[i];  dv[j] = sum_i P[i][j] dO[i]
-template <int DH>
+template <int DH, bool SP = false>
 __global__ __launch_bounds__(256) void k_attn_mfma_bwd_kv(cfp qkv, cfp probs, cfp dout, cfp ds, int S, int B, int D, int H, int bf,
                                                          float* __restrict__ dqkv) {
   extern __shared__ float sm[];
@@ -436,6 +584,39 @@ __global__ __launch_bounds__(256) void k_attn_mfma_bwd_kv(cfp qkv, cfp probs, cf
     at_stage<DH, AT_VP>(tq, qkv + h * DH, 3 * D, it * 64, S, B, b, bf);
     at_stage<DH, AT_VP>(td, dout + h * DH, D, it * 64, S, B, b, bf);
     __syncthreads();
+    if constexpr (SP) {
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib) {
+        if (it * 4 + ib * 2 < nt) {
+          float ads[8], ap[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int i = it * 64 + ib * 32 + lg * 8 + e;
+            const bool ok = i < S && j < S;
+            ads[e] = ok ? dsb[(size_t)i * S + j] : 0.f;
+            ap[e] = ok ? pb[(size_t)i * S + j] : 0.f;
+          }
+          uint4 dsh, dsl, ph, pl;
+          at_split8<false>(ads, dsh, dsl);
+          at_split8<false>(ap, ph, pl);
+#pragma unroll
+          for (int jn = 0; jn < DH / 16; ++jn) {
+            float wq[8], wd[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              wq[e] = tq[(ib * 32 + lg * 8 + e) * AT_VP + jn * 16 + li];
+              wd[e] = td[(ib * 32 + lg * 8 + e) * AT_VP + jn * 16 + li];
+            }
+            uint4 qh, ql, oh, ol;
+            at_split8<false>(wq, qh, ql);
+            at_split8<false>(wd, oh, ol);
+            dk[jn] = at_mma3<false>(dsh, dsl, qh, ql, dk[jn]);
+            dv[jn] = at_mma3<false>(ph, pl, oh, ol, dv[jn]);
+          }
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int is = 0; is < 4; ++is) {
       if (it * 4 + is < nt) {
@@ -488,13 +669,22 @@ static bool attn_mfma_prepare() {        // raise the dynamic LDS limit of the a
     auto set = [&](const void* f) { good = good && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; };
     set((const void*)k_attn_mfma_fwd<16>); set((const void*)k_attn_mfma_fwd<32>); set((const void*)k_attn_mfma_fwd<64>);
     set((const void*)k_attn_mfma_bwd_q<16>); set((const void*)k_attn_mfma_bwd_q<32>); set((const void*)k_attn_mfma_bwd_q<64>);
+    set((const void*)k_attn_mfma_fwd<32, true>); set((const void*)k_attn_mfma_fwd<64, true>);
+    set((const void*)k_attn_mfma_bwd_q<32, true>); set((const void*)k_attn_mfma_bwd_q<64, true>);
     return good;
   }();
   done[dev] = ok;
   return ok;
 }
-static int attn_pp(int S) { return ((S + 15) & ~15) + 8; }       // pitch of the per-wave P buffer: = 8 (mod 16) floats
-static size_t attn_mfma_lds(int S) { return (size_t)(64 * AT_KP + 4 * 16 * attn_pp(S)) * 4; }
+// pitch of the per-wave P buffer: = 8 (mod 16) floats; the split-precision kernels contract over 32 keys per instruction
+static int attn_pp(int S, bool sp = false) { return sp ? ((S + 31) & ~31) + 8 : ((S + 15) & ~15) + 8; }
+static size_t attn_mfma_lds(int S, bool sp = false) { return (size_t)(64 * AT_KP + 4 * 16 * attn_pp(S, sp)) * 4; }
+extern "C" int md_get_exact_fp32(void);
+// split-precision products (three 16-bit MFMAs per fp32 product) unless the library is in exact-fp32 mode; d_head >= 32
+static bool attn_split(int dh) {
+  static const bool off = [] { const char* e = getenv("MD_ATTN_SPLIT"); return e && atoi(e) == 0; }();
+  return !off && !md_get_exact_fp32() && dh >= 32;
+}
 
 // GELU.  kind 0: exact, 0.5 x (1 + erf(x / sqrt 2)) (nn.GELU, transformer.py:85); kind 1: the reference's own tanh form
 // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) (transformer.py:36-38).  bwd: dx = dy * gelu'(x).
@@ -614,11 +804,15 @@ extern "C" int md_attention_fwd(const float* qkv, const float* mask, const float
   if (attn_use_mfma(mask, drop, S, D, H)) {
     if (!attn_mfma_prepare()) return MD_ERR_LAUNCH;
     const dim3 grid(B * H, md_cdiv(S, 64));
-    const size_t l = attn_mfma_lds(S);
+    const bool sp = attn_split(D / H);
+    const size_t l = attn_mfma_lds(S, sp);
     const float sc = 1.f / sqrtf((float)(D / H));
-    const int bf = batch_first ? 1 : 0, pp = attn_pp(S);
+    const int bf = batch_first ? 1 : 0, pp = attn_pp(S, sp);
     hipStream_t st = (hipStream_t)stream;
-    switch (D / H) {
+    if (sp) {
+      if (D / H == 32) MD_KLAUNCH((k_attn_mfma_fwd<32, true>), grid, dim3(256), l, st, qkv, S, B, D, H, bf, sc, pp, probs, out);
+      else MD_KLAUNCH((k_attn_mfma_fwd<64, true>), grid, dim3(256), l, st, qkv, S, B, D, H, bf, sc, pp, probs, out);
+    } else switch (D / H) {
       case 16: MD_KLAUNCH(k_attn_mfma_fwd<16>, grid, dim3(256), l, st, qkv, S, B, D, H, bf, sc, pp, probs, out); break;
       case 32: MD_KLAUNCH(k_attn_mfma_fwd<32>, grid, dim3(256), l, st, qkv, S, B, D, H, bf, sc, pp, probs, out); break;
       default: MD_KLAUNCH(k_attn_mfma_fwd<64>, grid, dim3(256), l, st, qkv, S, B, D, H, bf, sc, pp, probs, out); break;
@@ -643,10 +837,21 @@ extern "C" int md_attention_bwd(const float* qkv, const float* probs, const floa
   if (attn_use_mfma(nullptr, drop, S, D, H)) {
     if (!attn_mfma_prepare()) return MD_ERR_LAUNCH;
     const dim3 grid(B * H, md_cdiv(S, 64));
-    const size_t la = attn_mfma_lds(S), lb = (size_t)2 * 64 * AT_VP * 4;
-    const int pp = attn_pp(S);
+    const bool sp = attn_split(D / H);
+    const size_t la = attn_mfma_lds(S, sp), lb = (size_t)2 * 64 * AT_VP * 4;
+    const int pp = attn_pp(S, sp);
     const float* dsc = ds_scratch;
-    switch (D / H) {
+    if (sp) {
+      if (D / H == 32) {
+        MD_KLAUNCH((k_attn_mfma_bwd_q<32, true>), grid, dim3(256), la, s, qkv, probs, dout, S, B, D, H, bf, scale, pp, ds_scratch, dqkv);
+        MD_CHECK_LAUNCH();
+        MD_KLAUNCH((k_attn_mfma_bwd_kv<32, true>), grid, dim3(256), lb, s, qkv, probs, dout, dsc, S, B, D, H, bf, dqkv);
+      } else {
+        MD_KLAUNCH((k_attn_mfma_bwd_q<64, true>), grid, dim3(256), la, s, qkv, probs, dout, S, B, D, H, bf, scale, pp, ds_scratch, dqkv);
+        MD_CHECK_LAUNCH();
+        MD_KLAUNCH((k_attn_mfma_bwd_kv<64, true>), grid, dim3(256), lb, s, qkv, probs, dout, dsc, S, B, D, H, bf, dqkv);
+      }
+    } else switch (D / H) {
       case 16:
         MD_KLAUNCH(k_attn_mfma_bwd_q<16>, grid, dim3(256), la, s, qkv, probs, dout, S, B, D, H, bf, scale, pp, ds_scratch, dqkv);
         MD_CHECK_LAUNCH();

@@ -1582,42 +1582,48 @@ int wgrad_patch_launch(const WgradPlan* p, const MdConvDesc* d, const float* src
 #define LB_M 128
 #define LB_K 32
 #define LB_P 80
-template <bool F16>
-__global__ __launch_bounds__(256) void k_linear_split(const float* __restrict__ A, int M, int K, const float* __restrict__ W, int Kp,
-                                                     int N16, float* __restrict__ C, int ldc, int accumulate, int npb) {
+// W8: eight waves on the same 128-row tile (two per SIMD, so one wave's staging arithmetic overlaps the other's MFMAs): waves 0-3 take
+// the first half of the column tiles, waves 4-7 the second; a thread then stages 8 floats per operand instead of 16.
+template <bool F16, bool W8>
+__global__ __launch_bounds__(W8 ? 512 : 256) void k_linear_split(const float* __restrict__ A, int M, int K, const float* __restrict__ W, int Kp,
+                                                                int N16, float* __restrict__ C, int ldc, int accumulate, int npb) {
   __shared__ __attribute__((aligned(16))) char lds[4 * LB_M * LB_P];
   char* aH = lds; char* aL = lds + LB_M * LB_P; char* bH = lds + 2 * LB_M * LB_P; char* bL = lds + 3 * LB_M * LB_P;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
+  constexpr int NQ = W8 ? 2 : 4;                        // float4s per operand and thread and stage
+  const int t = threadIdx.x, lane = t & 63, wave = (t >> 6) & 3, half = t >> 8, li = lane & 15, lg = lane >> 4;
   const int m0 = blockIdx.x * LB_M, n0 = blockIdx.y * npb;
   const int ncols = min(npb, N16 - n0), nt = ncols >> 4;
-  const int r = t >> 1, h = t & 1;                      // staging: row r, floats 16 h .. 16 h + 15 of the stage
+  const int r = W8 ? t >> 2 : t >> 1, h = W8 ? t & 3 : t & 1;      // staging: row r, floats 4 NQ h .. 4 NQ (h + 1) - 1 of the stage
   const bool arow = m0 + r < M, brow = r < ncols;
-  const float* ap = A + (size_t)(m0 + r) * K + h * 16;
-  const float* bp = W + (size_t)(n0 + r) * Kp + h * 16;
-  float4 ra[4], rb[4];
+  const float* ap = A + (size_t)(m0 + r) * K + h * 4 * NQ;
+  const float* bp = W + (size_t)(n0 + r) * Kp + h * 4 * NQ;
+  float4 ra[NQ], rb[NQ];
   auto load = [&](int kb) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = kb * LB_K + h * 16 + i * 4;
+    for (int i = 0; i < NQ; ++i) {
+      const int k = kb * LB_K + h * 4 * NQ + i * 4;
       ra[i] = (arow && k < K) ? *(const float4*)(ap + kb * LB_K + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
       rb[i] = brow ? *(const float4*)(bp + kb * LB_K + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  auto store = [&](const float4 (&v)[4], char* hi, char* lo) {
+  auto store = [&](const float4 (&v)[NQ], char* hi, char* lo) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < NQ / 2; ++q) {
       const float f[8] = {v[2 * q].x, v[2 * q].y, v[2 * q].z, v[2 * q].w, v[2 * q + 1].x, v[2 * q + 1].y, v[2 * q + 1].z, v[2 * q + 1].w};
       uint4 uh, ul;
       if (F16) split8_f16(f, uh, ul); else split8(f, uh, ul);
-      *(uint4*)(hi + r * LB_P + h * 32 + q * 16) = uh;
-      *(uint4*)(lo + r * LB_P + h * 32 + q * 16) = ul;
+      *(uint4*)(hi + r * LB_P + h * 8 * NQ + q * 16) = uh;
+      *(uint4*)(lo + r * LB_P + h * 8 * NQ + q * 16) = ul;
     }
   };
-  f32x4 acc[2][8];
+  constexpr int NJ = W8 ? 4 : 8;
+  const int jper = W8 ? (nt + 1) >> 1 : nt;
+  const int jlo = half * jper, jn = min(nt, jlo + jper) - jlo;      // this wave's column tiles: jlo .. jlo + jn - 1
+  f32x4 acc[2][NJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int nstages = Kp / LB_K;
   load(0);
   for (int kb = 0; kb < nstages; ++kb) {
@@ -1633,10 +1639,10 @@ __global__ __launch_bounds__(256) void k_linear_split(const float* __restrict__ 
       al[i] = *(const uint4*)(aL + (wave * 32 + i * 16 + li) * LB_P + lg * 16);
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (j < nt) {
-        const uint4 bh = *(const uint4*)(bH + (j * 16 + li) * LB_P + lg * 16);
-        const uint4 bl = *(const uint4*)(bL + (j * 16 + li) * LB_P + lg * 16);
+    for (int j = 0; j < NJ; ++j) {
+      if (j < jn) {
+        const uint4 bh = *(const uint4*)(bH + ((jlo + j) * 16 + li) * LB_P + lg * 16);
+        const uint4 bl = *(const uint4*)(bL + ((jlo + j) * 16 + li) * LB_P + lg * 16);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           acc[i][j] = mma<F16>(ah[i], bh, acc[i][j]);
@@ -1649,9 +1655,9 @@ __global__ __launch_bounds__(256) void k_linear_split(const float* __restrict__ 
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (j < nt) {
-        const int col = n0 + j * 16 + li;
+    for (int j = 0; j < NJ; ++j) {
+      if (j < jn) {
+        const int col = n0 + (jlo + j) * 16 + li;
         if (col < ldc) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -1676,11 +1682,17 @@ int linear_split_launch(int f16, const float* A, int M, int K, const float* W, i
   static const int off = getenv("MD_LINEAR_SPLIT") && atoi(getenv("MD_LINEAR_SPLIT")) == 0;
   if (off || (K & 3) || (Kp % LB_K) || (N16 & 15)) return MD_ERR_UNSUPPORTED;
   int npb = 128;
-  static const int fill = getenv("MD_LINEAR_FILL") ? atoi(getenv("MD_LINEAR_FILL")) : 512;
+  static const int fill = getenv("MD_LINEAR_FILL") ? atoi(getenv("MD_LINEAR_FILL")) : 256;   // ViViT cfg3 captured step: 512 -> 4.62 ms, 256 -> 4.38, 130 / 64 -> 4.43
   while (md_cdiv(M, LB_M) * md_cdiv(N16, npb) < fill && npb > 32) npb >>= 1;
   const dim3 grid(md_cdiv(M, LB_M), md_cdiv(N16, npb));
-  if (f16) MD_KLAUNCH(k_linear_split<true>, grid, dim3(256), 0, s, A, M, K, W, Kp, N16, C, ldc, accumulate, npb);
-  else MD_KLAUNCH(k_linear_split<false>, grid, dim3(256), 0, s, A, M, K, W, Kp, N16, C, ldc, accumulate, npb);
+  static const int w8 = getenv("MD_LINEAR_W8") ? atoi(getenv("MD_LINEAR_W8")) : 1;
+  if (w8 && npb >= 32) {
+    if (f16) MD_KLAUNCH((k_linear_split<true, true>), grid, dim3(512), 0, s, A, M, K, W, Kp, N16, C, ldc, accumulate, npb);
+    else MD_KLAUNCH((k_linear_split<false, true>), grid, dim3(512), 0, s, A, M, K, W, Kp, N16, C, ldc, accumulate, npb);
+  } else {
+    if (f16) MD_KLAUNCH((k_linear_split<true, false>), grid, dim3(256), 0, s, A, M, K, W, Kp, N16, C, ldc, accumulate, npb);
+    else MD_KLAUNCH((k_linear_split<false, false>), grid, dim3(256), 0, s, A, M, K, W, Kp, N16, C, ldc, accumulate, npb);
+  }
   MD_CHECK_LAUNCH();
   return MD_OK;
 }

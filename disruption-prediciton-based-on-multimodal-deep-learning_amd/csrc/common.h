@@ -69,6 +69,10 @@ int patch_launch(const PatchPlan* p, const float* src, const float* ps, const fl
 bool patch_can_fuse(const PatchPlan* p);
 
 struct WgradPlan;
+// While one of these is alive on the calling thread, weight-gradient plans are the ones sized to run BESIDE another kernel chain
+// (the R(2+1)D executor's side stream: 160 of 256 CUs); otherwise a weight gradient takes the whole chip.
+extern thread_local int g_wgrad_beside;
+struct WgradBeside { WgradBeside() { ++g_wgrad_beside; } ~WgradBeside() { --g_wgrad_beside; } };
 const WgradPlan* wgrad_lookup(const MdConvDesc* d, int xpitch = 0, int xc0 = 0, int dw_cin = 0);   // xpitch != 0: X = channel slice of a wider tensor
 size_t wgrad_patch_workspace_floats(const WgradPlan* p);
 bool wgrad_plan_xsplit_ok(const WgradPlan* p);

@@ -1476,14 +1476,16 @@ static int wgrad_wgs_per_cu(const WGeom& g, size_t lds) {
   return nb > 2 ? 2 : nb;
 }
 
+thread_local int g_wgrad_beside = 0;
 const WgradPlan* wgrad_lookup(const MdConvDesc* d, int xpitch, int xc0, int dw_cin) {
   if (g_exact_fp32.load()) return nullptr;
   static const int dis = getenv("MD_PATCH_WGRAD") && atoi(getenv("MD_PATCH_WGRAD")) == 0;
   if (dis) return nullptr;
   static std::mutex mu;
-  static std::map<std::array<int, 21>, WgradPlan*> cache;
-  std::array<int, 21> key = {d->N, d->Ti, d->Hi, d->Wi, d->Cin, d->To, d->Ho, d->Wo, d->Cout, d->kt, d->kh, d->kw,
-                             d->st, d->sh, d->sw, d->pt, d->ph, d->pw, xpitch, xc0, dw_cin};
+  static std::map<std::array<int, 22>, WgradPlan*> cache;
+  const int beside = g_wgrad_beside > 0 ? 1 : 0;
+  std::array<int, 22> key = {d->N, d->Ti, d->Hi, d->Wi, d->Cin, d->To, d->Ho, d->Wo, d->Cout, d->kt, d->kh, d->kw,
+                             d->st, d->sh, d->sw, d->pt, d->ph, d->pw, xpitch, xc0, dw_cin, beside};
   std::lock_guard<std::mutex> lock(mu);
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
@@ -1496,7 +1498,10 @@ const WgradPlan* wgrad_lookup(const MdConvDesc* d, int xpitch, int xc0, int dw_c
     // chain (plan.hip); leaving part of the chip to that chain measured best at 160 of 256 (96: 992, 128: 1088,
     // 160: 1097, 192: 1085, 256: 1068 clips/s); with the side stream switched off the kernel takes the whole chip.
     static const int side_off = getenv("MD_WGRAD_STREAM") && atoi(getenv("MD_WGRAD_STREAM")) == 0;
-    static const int fill = getenv("MD_WGRAD_FILL") ? atoi(getenv("MD_WGRAD_FILL")) : (side_off ? 256 : 160);
+    // Outside the executor (the composable models: a weight gradient runs alone on its stream) the kernel takes the whole chip as
+    // well: ViViT cfg3 captured step 4.23 -> 4.14 ms at 256 (512: 4.21, 1024: 4.24).
+    static const int fill_env = getenv("MD_WGRAD_FILL") ? atoi(getenv("MD_WGRAD_FILL")) : 0;
+    const int fill = fill_env ? fill_env : ((side_off || !beside) ? 256 : 160);
     const int occ = wgrad_wgs_per_cu(g, lds);
     // eight-wave form of the prefetching kernel where only one 4-wave workgroup would fit a CU
     static const int w8_env = getenv("MD_WGRAD_W8") ? atoi(getenv("MD_WGRAD_W8")) : 1;

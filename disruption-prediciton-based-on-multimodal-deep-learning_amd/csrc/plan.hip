@@ -135,6 +135,8 @@ static void add_st_conv(MdPlan* P, int Ti, int Hi, int Wi, int cin, int cout, in
 
 extern "C" int md_plan_create(int32_t B, int32_t T, int32_t H, int32_t W, const int32_t* layer_sizes, float alpha,
                               MdPlan** out) {
+  WgradBeside beside_hint;          // workspace sizes below are those of the side-stream weight-gradient plans
+
   if (!layer_sizes || !out) return MD_ERR_NULL;
   if (B <= 0 || T <= 0 || H <= 0 || W <= 0) return MD_ERR_BAD_SHAPE;
   for (int i = 0; i < 4; ++i) if (layer_sizes[i] < 1) return MD_ERR_BAD_SHAPE;
@@ -580,6 +582,8 @@ static int block_backward(MdPlan* P, float* ws, const Block& b, const float* con
 extern "C" int md_plan_backward_range(MdPlan* P, const float* dfeat, const float* const* w, const float* const* gamma,
                                       float* const* dw, float* const* dgamma, float* const* dbeta, void* workspace,
                                       int32_t stage_hi, int32_t stage_lo, void* stream) {
+  WgradBeside beside_hint;
+
   if (!P || !w || !dw || !dgamma || !dbeta || !workspace) return MD_ERR_NULL;
   (void)gamma;
   if (stage_hi > 4 || stage_lo < 0 || stage_lo > stage_hi) return MD_ERR_BAD_SHAPE;
@@ -608,6 +612,8 @@ extern "C" int md_plan_backward_range(MdPlan* P, const float* dfeat, const float
 
 extern "C" int md_plan_backward(MdPlan* P, const float* dfeat, const float* const* w, const float* const* gamma,
                                 float* const* dw, float* const* dgamma, float* const* dbeta, void* workspace, void* stream) {
+  WgradBeside beside_hint;
+
   return md_plan_backward_range(P, dfeat, w, gamma, dw, dgamma, dbeta, workspace, 4, 0, stream);
 }
 

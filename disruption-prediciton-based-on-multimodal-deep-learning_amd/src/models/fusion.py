@@ -12,6 +12,8 @@ from typing import Literal
 import torch
 import torch.nn as nn
 
+import os
+
 from ..utils import streams
 from .MLSTM_FCN import MLSTM_FCN
 from .MultiModal import _classifier, _connector, _make_classifier, _make_connector, _param_table
@@ -19,6 +21,10 @@ from .R2Plus1D import R2Plus1DClassifier, R2Plus1DNet
 from .slowfast import SlowFast
 from .transformer import Transformer
 from .ViViT import ViViT
+
+
+_GRAPH_BRANCH = os.environ.get("MD_GRAPH_BRANCH") == "1"
+_GRAPH_BRANCH_FORK = os.environ.get("MD_GRAPH_BRANCH_FORK") == "1"     # the graphed branch on the side stream as well
 
 
 def _vision_adapter(m: nn.Module):
@@ -73,24 +79,45 @@ class FusionGB(nn.Module):
             return self.vis_model(x_vis)
         elif self.use_stream == "0D":
             return self.ts_model(x_ts)
-        if streams.enabled(x_vis) and x_ts.is_cuda:
+        if streams.enabled(x_vis) and x_ts.is_cuda and not (_GRAPH_BRANCH and not _GRAPH_BRANCH_FORK and torch.is_grad_enabled()):
             # the 0D encoder and its head on a side stream, beside the video encoder (src/utils/streams.py)
             with streams.fork(x_vis.device, 1, (x_ts,)) as f:
-                ts_latent = self._ts[0](x_ts)
-                out_ts = self._ts[1](ts_latent)
+                ts_latent, out_ts = self._ts_branch(x_ts)
             vis_latent = self._vis[0](x_vis)
             out_vis = self._vis[1](vis_latent)
             f.join(ts_latent, out_ts)
         else:
             vis_latent = self._vis[0](x_vis)
-            ts_latent = self._ts[0](x_ts)
+            ts_latent, out_ts = self._ts_branch(x_ts)
             out_vis = self._vis[1](vis_latent)
-            out_ts = self._ts[1](ts_latent)
         self.vis_latent = (vis_latent,)
         self.ts_latent = (ts_latent,)
         x = _connector(torch.cat([vis_latent, ts_latent], axis=1), self.connector)
         out_multi = _classifier(x, self.classifier)
         return out_multi if self.use_stream == 'multi' else (out_multi, out_vis, out_ts)
+
+    def _ts_eager(self, x_ts: torch.Tensor):
+        ts_latent = self._ts[0](x_ts)
+        return ts_latent, self._ts[1](ts_latent)
+
+    def _ts_branch(self, x_ts: torch.Tensor):
+        """(latent, logits) of the 0D encoder.  MD_GRAPH_BRANCH=1: its forward and its backward are replayed from HIP graphs
+        (src/utils/graphed.py::GraphedBranch) while the rest of the step stays eager -- for the pairs whose video trunk runs from the
+        C++ executor and whose 0D encoder is a few hundred tiny launches (cfg4)."""
+        if not (_GRAPH_BRANCH and x_ts.is_cuda and torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing()):
+            return self._ts_eager(x_ts)
+        gbr = self.__dict__.get("_md_ts_graph")
+        if gbr is None:
+            from ..utils.graphed import GraphedBranch
+            try:
+                gbr = GraphedBranch(self.ts_model, self._ts_eager, (x_ts,))
+            except RuntimeError as e:
+                print("FusionGB | MD_GRAPH_BRANCH: capture refused, 0D encoder stays eager (%s)" % str(e).split("\n")[0][:200])
+                gbr = False
+            self.__dict__["_md_ts_graph"] = gbr
+        if gbr is False or not gbr.matches((x_ts,), self.training):
+            return self._ts_eager(x_ts)
+        return gbr(x_ts)
 
     def encode(self, x_vis: torch.Tensor, x_0D: torch.Tensor):
         with torch.no_grad():

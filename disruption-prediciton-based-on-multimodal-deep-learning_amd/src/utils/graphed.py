@@ -115,3 +115,47 @@ class GraphedStep:
         for mod, k, v in self.published:                   # (an eager validation pass in between re-pointed them)
             setattr(mod, k, v)
         return self.outputs, self.loss
+
+
+class GraphedBranch:
+    """One branch of a model (a callable over tensors that owns parameters, e.g. the 0D encoder + its head of a fusion model) with
+    its forward and its backward each replayed from a HIP graph, inside an otherwise eager step: ``torch.cuda.make_graphed_callables``
+    over a small wrapper module.  For the branches whose step is a few hundred tiny launches issued from Python next to a trunk
+    that runs from the C++ executor (cfg4: R(2+1)D + Transformer-0D -- the trunk queues in 2.5 ms, the 0D encoder cost the host
+    5 ms).  Fixed input shape (another shape falls back to the eager branch); NoiseLayers are fed as in ``GraphedStep`` (one pinned
+    staging buffer, refilled from the CPU generator before every replay)."""
+
+    class _Wrap(torch.nn.Module):
+        def __init__(self, owner: torch.nn.Module, fn: Callable):
+            super().__init__()
+            self.owner = owner                 # registers the parameters (make_graphed_callables treats them as graph inputs)
+            self.fn = fn
+
+        def forward(self, *xs):
+            return self.fn(*xs)
+
+    def __init__(self, owner: torch.nn.Module, fn: Callable, example_inputs: Sequence[torch.Tensor]):
+        self.noise_layers = [mod for mod in owner.modules() if type(mod).__name__ == "NoiseLayer"]
+        for mod in self.noise_layers:
+            mod.__dict__["_graph_mode"] = True
+            mod.__dict__.pop("_static", None)
+        self.shapes = tuple(tuple(t.shape) for t in example_inputs)
+        self._done = torch.cuda.Event()
+        self.training = owner.training
+        wrap = GraphedBranch._Wrap(owner, fn)
+        wrap.train(owner.training)
+        samples = tuple(t.detach().clone() for t in example_inputs)
+        self.call = torch.cuda.make_graphed_callables(wrap, samples)
+
+    def matches(self, inputs: Sequence[torch.Tensor], training: bool) -> bool:
+        return training == self.training and tuple(tuple(t.shape) for t in inputs) == self.shapes
+
+    def __call__(self, *inputs):
+        if self.noise_layers:
+            self._done.synchronize()
+            for mod in self.noise_layers:
+                mod.refresh_static()
+        out = self.call(*inputs)
+        if self.noise_layers:
+            self._done.record()
+        return out

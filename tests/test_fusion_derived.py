@@ -210,3 +210,48 @@ def test_encoders_on_separate_streams_are_bit_identical_to_one_stream(tag):
                 assert torch.equal(got[2][k], ref[2][k]), k
     finally:
         streams._ENABLED = old
+
+
+@pytest.mark.gpu
+def test_graphed_0d_branch_matches_the_eager_step():
+    """MD_GRAPH_BRANCH=1 (src/models/fusion.py): forward and backward of the 0D encoder + head replayed from HIP graphs inside an
+    otherwise eager step (R(2+1)D trunk + Transformer-0D, no dropout, NoiseLayer off so that the capture's warm-up steps do not shift
+    the CPU generator): outputs and every parameter gradient bit-identical to the eager step, on three successive batches."""
+    import src.models.fusion as fu
+    torch.manual_seed(21)
+    m = _native("cfg4").cuda().train()
+    for mod in m.modules():
+        if type(mod).__name__ == "NoiseLayer":
+            mod.std = 0.0
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    batches = [(torch.randn(4, 3, 5, 24, 24, device="cuda"), torch.randn(4, 5, 6, device="cuda")) for _ in range(3)]
+
+    def run(flag):
+        old = fu._GRAPH_BRANCH
+        fu._GRAPH_BRANCH = flag
+        m.__dict__.pop("_md_ts_graph", None)
+        m.load_state_dict(sd)
+        res = []
+        try:
+            for xv, xt in batches:
+                for p in m.parameters():
+                    p.grad = None
+                outs = m(xv, xt)
+                sum(o.square().sum() for o in outs).backward()
+                torch.cuda.synchronize()
+                res.append(([o.detach().clone() for o in outs], {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}))
+            used = m.__dict__.get("_md_ts_graph")
+        finally:
+            fu._GRAPH_BRANCH = old
+            m.__dict__.pop("_md_ts_graph", None)
+        return res, used
+
+    ref, used0 = run(False)
+    got, used1 = run(True)
+    assert used0 is None and used1 not in (None, False)
+    for (o0, g0), (o1, g1) in zip(ref, got):
+        for a, b in zip(o0, o1):
+            assert torch.equal(a, b)
+        assert g0.keys() == g1.keys()
+        for k in g0:
+            assert torch.equal(g0[k], g1[k]), k

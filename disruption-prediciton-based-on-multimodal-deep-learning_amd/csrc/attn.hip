@@ -398,7 +398,9 @@ __device__ __forceinline__ float at_group_sum(float v) {
   return v;
 }
 
-template <int DH, bool SP = false>
+// LSE (split form only): `probs` receives one value per query row, max + log(sum) of its scores, instead of the S x S matrix --
+// the backward kernels k_attn_lse_bwd_* recompute P from q, k and that value.
+template <int DH, bool SP = false, bool LSE = false>
 __global__ __launch_bounds__(256) void k_attn_mfma_fwd(cfp qkv, int S, int B, int D, int H, int bf, float scale, int pp,
                                                       float* __restrict__ probs, float* __restrict__ out) {
   extern __shared__ float sm[];
@@ -450,14 +452,16 @@ __global__ __launch_bounds__(256) void k_attn_mfma_fwd(cfp qkv, int S, int B, in
     for (int t = 0; t < AT_MAXT; ++t) {
       if (t < nt) { const float e = (16 * t + li < S) ? expf(acc[t][r] - mx) : 0.f; acc[t][r] = e; sum += e; }
     }
-    const float inv = 1.f / at_group_sum(sum);
+    const float tot = at_group_sum(sum);
+    const float inv = 1.f / tot;
     const int i = q0 + 4 * lg + r;
+    if (LSE && li == 0 && i < S) probs[(size_t)bh * S + i] = mx + logf(tot);
 #pragma unroll
     for (int t = 0; t < AT_MAXT; ++t) {
       if (t < nt) {
         const float pv = acc[t][r] * inv;
         pw[(4 * lg + r) * pp + 16 * t + li] = pv;
-        if (i < S && 16 * t + li < S) probs[((size_t)bh * S + i) * S + 16 * t + li] = pv;
+        if (!LSE && i < S && 16 * t + li < S) probs[((size_t)bh * S + i) * S + 16 * t + li] = pv;
       }
     }
   }
@@ -651,6 +655,197 @@ __global__ __launch_bounds__(256) void k_attn_mfma_bwd_kv(cfp qkv, cfp probs, cf
     }
   }
 }
+// ---- backward without the S x S matrices: P is recomputed from q, k and the forward pass's per-row log-sum-exp (the same fp16
+// split products as the forward pass), so neither P nor dS travels through memory (cfg3: 52 MB each, per attention call).
+// pass A per 16 queries: S = (q scale) K^T, dP = dO V^T, P = exp(S - lse), delta = rowsum(P dP) -> delta_out, dS = P (dP - delta) scale,
+// dq = dS K.
+#define AT_TP 72          // pitch of the per-wave 16 x 64 transposed blocks of pass B
+template <int DH>
+__global__ __launch_bounds__(256) void k_attn_lse_bwd_q(cfp qkv, cfp lse, cfp dout, int S, int B, int D, int H, int bf, float scale, int pp,
+                                                       float* __restrict__ delta_out, float* __restrict__ dqkv) {
+  extern __shared__ float sm[];
+  float* tile = sm;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+  float* pw = sm + 64 * AT_KP + wave * 16 * pp;
+  const int bh = blockIdx.x, b = bh / H, h = bh - b * H, nt = (S + 15) >> 4;
+  const int q0 = blockIdx.y * 64 + wave * 16;
+  f32x4 acs[AT_MAXT], acd[AT_MAXT];
+#pragma unroll
+  for (int t = 0; t < AT_MAXT; ++t) { acs[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acd[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  {
+    uint4 ah[DH / 32], al[DH / 32];
+    const int i = q0 + li;
+    const size_t row = bf ? (size_t)b * S + i : (size_t)i * B + b;
+#pragma unroll
+    for (int s = 0; s < DH / 32; ++s) {
+      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (i < S) {
+        const float* p = qkv + row * 3 * D + h * DH + s * 32 + lg * 8;
+        *(float4*)v = *(const float4*)p; *(float4*)(v + 4) = *(const float4*)(p + 4);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= scale;
+      at_split8<true>(v, ah[s], al[s]);
+    }
+    at_scores_sp<DH, true>(acs, ah, al, tile, qkv + D + h * DH, 3 * D, S, B, b, bf, nt, li, lg);
+#pragma unroll
+    for (int s = 0; s < DH / 32; ++s) {
+      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (i < S) {
+        const float* p = dout + row * D + h * DH + s * 32 + lg * 8;
+        *(float4*)v = *(const float4*)p; *(float4*)(v + 4) = *(const float4*)(p + 4);
+      }
+      at_split8<false>(v, ah[s], al[s]);
+    }
+    at_scores_sp<DH, false>(acd, ah, al, tile, qkv + 2 * D + h * DH, 3 * D, S, B, b, bf, nt, li, lg);
+  }
+  AtRegs<DH> vpre;
+  at_fetch<DH>(vpre, qkv + D + h * DH, 3 * D, 0, S, B, b, bf);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = q0 + 4 * lg + r;
+    const float l = i < S ? lse[(size_t)bh * S + i] : 0.f;
+    float pr[AT_MAXT];
+    float dot = 0.f;
+#pragma unroll
+    for (int t = 0; t < AT_MAXT; ++t) {
+      pr[t] = 0.f;
+      if (t < nt) {
+        if (i < S && 16 * t + li < S) pr[t] = expf(acs[t][r] - l);
+        dot = fmaf(acd[t][r], pr[t], dot);
+      }
+    }
+    dot = at_group_sum(dot);
+    if (li == 0 && i < S) delta_out[(size_t)bh * S + i] = dot;
+#pragma unroll
+    for (int t = 0; t < AT_MAXT; ++t) {
+      if (t < nt) pw[(4 * lg + r) * pp + 16 * t + li] = pr[t] * (acd[t][r] - dot) * scale;
+    }
+  }
+  if (nt & 1) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pw[(4 * lg + r) * pp + 16 * nt + li] = 0.f;
+  }
+  f32x4 o[DH / 16];
+  at_apply_sp<DH, false>(o, pw, pp, tile, vpre, qkv + D + h * DH, 3 * D, S, B, b, bf, nt, li, lg);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = q0 + 4 * lg + r;
+    if (i < S) {
+      float* dst = dqkv + (bf ? (size_t)b * S + i : (size_t)i * B + b) * 3 * D + h * DH + li;
+#pragma unroll
+      for (int jn = 0; jn < DH / 16; ++jn) dst[jn * 16] = o[jn][r];
+    }
+  }
+}
+// pass B per 16 keys j: for every block of 64 queries, S^T = K (q scale)^T and dP^T = V dO^T for the wave's keys (the staged
+// query / dO rows are the B operands), P^T = exp(S^T - lse_i), dS^T = P^T (dP^T - delta_i) scale; both go through the wave's LDS
+// blocks to become A operands of dv += P^T dO and dk += dS^T q.
+template <int DH>
+__global__ __launch_bounds__(256) void k_attn_lse_bwd_kv(cfp qkv, cfp lse, cfp delta, cfp dout, int S, int B, int D, int H, int bf, float scale,
+                                                        float* __restrict__ dqkv) {
+  extern __shared__ float sm[];
+  float* tq = sm;                      // 64 x AT_VP
+  float* td = sm + 64 * AT_VP;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+  float* pT = sm + 2 * 64 * AT_VP + wave * 2 * 16 * AT_TP;
+  float* dsT = pT + 16 * AT_TP;
+  const int bh = blockIdx.x, b = bh / H, h = bh - b * H, nt = (S + 15) >> 4;
+  const int j0 = blockIdx.y * 64 + wave * 16;
+  uint4 kh[DH / 32], kl[DH / 32], vh[DH / 32], vl[DH / 32];
+  {
+    const int j = j0 + li;
+    const size_t row = bf ? (size_t)b * S + j : (size_t)j * B + b;
+#pragma unroll
+    for (int s = 0; s < DH / 32; ++s) {
+      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, w[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (j < S) {
+        const float* p = qkv + row * 3 * D + D + h * DH + s * 32 + lg * 8;
+        *(float4*)v = *(const float4*)p; *(float4*)(v + 4) = *(const float4*)(p + 4);
+        *(float4*)w = *(const float4*)(p + D); *(float4*)(w + 4) = *(const float4*)(p + D + 4);
+      }
+      at_split8<true>(v, kh[s], kl[s]);
+      at_split8<false>(w, vh[s], vl[s]);
+    }
+  }
+  f32x4 dk[DH / 16], dv[DH / 16];
+#pragma unroll
+  for (int jn = 0; jn < DH / 16; ++jn) { dk[jn] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[jn] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  for (int it = 0; it * 4 < nt; ++it) {
+    __syncthreads();
+    at_stage<DH, AT_VP>(tq, qkv + h * DH, 3 * D, it * 64, S, B, b, bf);
+    at_stage<DH, AT_VP>(td, dout + h * DH, D, it * 64, S, B, b, bf);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      f32x4 st = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int i = it * 64 + 16 * t + li;          // this lane's query column
+      if (it * 4 + t < nt) {
+#pragma unroll
+        for (int s = 0; s < DH / 32; ++s) {
+          const float* pq = tq + (16 * t + li) * AT_VP + s * 32 + lg * 8;
+          const float* pd = td + (16 * t + li) * AT_VP + s * 32 + lg * 8;
+          float v[8], w[8];
+          *(float4*)v = *(const float4*)pq; *(float4*)(v + 4) = *(const float4*)(pq + 4);
+          *(float4*)w = *(const float4*)pd; *(float4*)(w + 4) = *(const float4*)(pd + 4);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= scale;
+          uint4 qh, ql, oh, ol;
+          at_split8<true>(v, qh, ql);
+          at_split8<false>(w, oh, ol);
+          st = at_mma3<true>(kh[s], kl[s], qh, ql, st);
+          dp = at_mma3<false>(vh[s], vl[s], oh, ol, dp);
+        }
+      }
+      const bool iv = i < S;
+      const float l = iv ? lse[(size_t)bh * S + i] : 0.f, de = iv ? delta[(size_t)bh * S + i] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = iv && j0 + 4 * lg + r < S;
+        const float pv = ok ? expf(st[r] - l) : 0.f;
+        pT[(4 * lg + r) * AT_TP + 16 * t + li] = pv;
+        dsT[(4 * lg + r) * AT_TP + 16 * t + li] = pv * (dp[r] - de) * scale;
+      }
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      if (it * 4 + kb * 2 < nt) {
+        float ap[8], ads[8];
+        const float* pp_ = pT + li * AT_TP + kb * 32 + lg * 8;
+        const float* pd_ = dsT + li * AT_TP + kb * 32 + lg * 8;
+        *(float4*)ap = *(const float4*)pp_; *(float4*)(ap + 4) = *(const float4*)(pp_ + 4);
+        *(float4*)ads = *(const float4*)pd_; *(float4*)(ads + 4) = *(const float4*)(pd_ + 4);
+        uint4 ph, pl, dsh, dsl;
+        at_split8<false>(ap, ph, pl);
+        at_split8<false>(ads, dsh, dsl);
+#pragma unroll
+        for (int jn = 0; jn < DH / 16; ++jn) {
+          float wq[8], wd[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            wq[e] = tq[(kb * 32 + lg * 8 + e) * AT_VP + jn * 16 + li];
+            wd[e] = td[(kb * 32 + lg * 8 + e) * AT_VP + jn * 16 + li];
+          }
+          uint4 qh, ql, oh, ol;
+          at_split8<false>(wq, qh, ql);
+          at_split8<false>(wd, oh, ol);
+          dk[jn] = at_mma3<false>(dsh, dsl, qh, ql, dk[jn]);
+          dv[jn] = at_mma3<false>(ph, pl, oh, ol, dv[jn]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int jj = j0 + 4 * lg + r;
+    if (jj < S) {
+      float* dst = dqkv + (bf ? (size_t)b * S + jj : (size_t)jj * B + b) * 3 * D + h * DH + li;
+#pragma unroll
+      for (int jn = 0; jn < DH / 16; ++jn) { dst[D + jn * 16] = dk[jn][r]; dst[2 * D + jn * 16] = dv[jn][r]; }
+    }
+  }
+}
+
 static bool attn_use_mfma(const float* mask, const float* drop, int S, int D, int H) {
   static const bool off = [] { const char* e = getenv("MD_ATTN_SCALAR"); return e && atoi(e) != 0; }();
   const int dh = D / H;
@@ -670,6 +865,9 @@ static bool attn_mfma_prepare() {        // raise the dynamic LDS limit of the a
     set((const void*)k_attn_mfma_fwd<16>); set((const void*)k_attn_mfma_fwd<32>); set((const void*)k_attn_mfma_fwd<64>);
     set((const void*)k_attn_mfma_bwd_q<16>); set((const void*)k_attn_mfma_bwd_q<32>); set((const void*)k_attn_mfma_bwd_q<64>);
     set((const void*)k_attn_mfma_fwd<32, true>); set((const void*)k_attn_mfma_fwd<64, true>);
+    set((const void*)k_attn_mfma_fwd<32, true, true>); set((const void*)k_attn_mfma_fwd<64, true, true>);
+    set((const void*)k_attn_lse_bwd_q<32>); set((const void*)k_attn_lse_bwd_q<64>);
+    set((const void*)k_attn_lse_bwd_kv<32>); set((const void*)k_attn_lse_bwd_kv<64>);
     set((const void*)k_attn_mfma_bwd_q<32, true>); set((const void*)k_attn_mfma_bwd_q<64, true>);
     return good;
   }();
@@ -824,6 +1022,52 @@ extern "C" int md_attention_fwd(const float* qkv, const float* mask, const float
   if (lds > 60000) return MD_ERR_UNSUPPORTED;
   MD_KLAUNCH(k_attn_fwd, dim3(B * H, md_cdiv(S, ATT_RB)), dim3(256), lds, (hipStream_t)stream, qkv, mask, drop, S, B, D, H,
              batch_first ? 1 : 0, 1.f / sqrtf((float)(D / H)), probs, out);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+// ---- recomputing form (no S x S matrices): see k_attn_lse_bwd_*.  Unmasked, dropout-free attention in split precision only.
+extern "C" int32_t md_attention_lse_supported(int32_t S, int32_t D, int32_t H) {
+  static const bool off = [] { const char* e = getenv("MD_ATTN_LSE"); return e && atoi(e) == 0; }();
+  if (off || S <= 0 || D <= 0 || H <= 0 || D % H) return 0;
+  return attn_use_mfma(nullptr, nullptr, S, D, H) && attn_split(D / H) ? 1 : 0;
+}
+extern "C" int md_attention_lse_fwd(const float* qkv, int32_t S, int32_t B, int32_t D, int32_t H, int32_t batch_first, float* lse,
+                                    float* out, void* stream) {
+  if (!qkv || !lse || !out) return MD_ERR_NULL;
+  if (S <= 0 || B <= 0 || D <= 0 || H <= 0 || D % H) return MD_ERR_BAD_SHAPE;
+  if (!md_attention_lse_supported(S, D, H)) return MD_ERR_UNSUPPORTED;
+  if (!attn_mfma_prepare()) return MD_ERR_LAUNCH;
+  const dim3 grid(B * H, md_cdiv(S, 64));
+  const size_t l = attn_mfma_lds(S, true);
+  const float sc = 1.f / sqrtf((float)(D / H));
+  const int bf = batch_first ? 1 : 0, pp = attn_pp(S, true);
+  hipStream_t st = (hipStream_t)stream;
+  if (D / H == 32) MD_KLAUNCH((k_attn_mfma_fwd<32, true, true>), grid, dim3(256), l, st, qkv, S, B, D, H, bf, sc, pp, lse, out);
+  else MD_KLAUNCH((k_attn_mfma_fwd<64, true, true>), grid, dim3(256), l, st, qkv, S, B, D, H, bf, sc, pp, lse, out);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+extern "C" int md_attention_lse_bwd(const float* qkv, const float* lse, const float* dout, int32_t S, int32_t B, int32_t D, int32_t H,
+                                    int32_t batch_first, float* dqkv, float* delta, void* stream) {
+  if (!qkv || !lse || !dout || !dqkv || !delta) return MD_ERR_NULL;
+  if (S <= 0 || B <= 0 || D <= 0 || H <= 0 || D % H) return MD_ERR_BAD_SHAPE;
+  if (!md_attention_lse_supported(S, D, H)) return MD_ERR_UNSUPPORTED;
+  if (!attn_mfma_prepare()) return MD_ERR_LAUNCH;
+  const dim3 grid(B * H, md_cdiv(S, 64));
+  const size_t la = attn_mfma_lds(S, true), lb = (size_t)(2 * 64 * AT_VP + 4 * 2 * 16 * AT_TP) * 4;
+  const float sc = 1.f / sqrtf((float)(D / H));
+  const int bf = batch_first ? 1 : 0, pp = attn_pp(S, true);
+  hipStream_t st = (hipStream_t)stream;
+  const float* de = delta;
+  if (D / H == 32) {
+    MD_KLAUNCH(k_attn_lse_bwd_q<32>, grid, dim3(256), la, st, qkv, lse, dout, S, B, D, H, bf, sc, pp, delta, dqkv);
+    MD_CHECK_LAUNCH();
+    MD_KLAUNCH(k_attn_lse_bwd_kv<32>, grid, dim3(256), lb, st, qkv, lse, de, dout, S, B, D, H, bf, sc, dqkv);
+  } else {
+    MD_KLAUNCH(k_attn_lse_bwd_q<64>, grid, dim3(256), la, st, qkv, lse, dout, S, B, D, H, bf, sc, pp, delta, dqkv);
+    MD_CHECK_LAUNCH();
+    MD_KLAUNCH(k_attn_lse_bwd_kv<64>, grid, dim3(256), lb, st, qkv, lse, de, dout, S, B, D, H, bf, sc, dqkv);
+  }
   MD_CHECK_LAUNCH();
   return MD_OK;
 }

@@ -122,6 +122,9 @@ SIGNATURES = {
     "md_add_layernorm_bwd": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _I32, _P, _P, _P, _P, _P]),
     "md_attention_fwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
     "md_attention_bwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
+    "md_attention_lse_supported": (C.c_int32, [_I32, _I32, _I32]),
+    "md_attention_lse_fwd": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
+    "md_attention_lse_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
     "md_elu": (C.c_int, [_P, _P, _F, C.c_int64, _P, _P]),
     "md_lstm_rec_supported": (C.c_int, [_I32]),
     "md_lstm_rec_fwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P]),

@@ -717,15 +717,31 @@ class AttentionFunction(torch.autograd.Function):
         ops.require_cuda(qkv, mask, drop)
         (B, S, D3) = qkv.shape if batch_first else (qkv.shape[1], qkv.shape[0], qkv.shape[2])
         D = D3 // 3
+        ctx.heads = int(heads); ctx.has_drop = drop is not None; ctx.bf = bool(batch_first)
+        ctx.lse = mask is None and drop is None and bool(N.lib().md_attention_lse_supported(S, D, int(heads)))
+        if ctx.lse:        # no S x S matrices: one log-sum-exp per query row, the backward recomputes the probabilities
+            lse = torch.empty((B * heads, S), device=qkv.device); out = torch.empty(qkv.shape[:2] + (D,), device=qkv.device)
+            N.check(N.lib().md_attention_lse_fwd(ops._p(qkv), S, B, D, int(heads), int(batch_first), ops._p(lse), ops._p(out),
+                                                 ops._stream()), "md_attention_lse_fwd")
+            ctx.save_for_backward(qkv, lse)
+            return out
         probs = torch.empty((B * heads, S, S), device=qkv.device); out = torch.empty(qkv.shape[:2] + (D,), device=qkv.device)
         N.check(N.lib().md_attention_fwd(ops._p(qkv), ops._p(mask), ops._p(drop), S, B, D, int(heads), int(batch_first), ops._p(probs),
                                          ops._p(out), ops._stream()), "md_attention_fwd")
         ctx.save_for_backward(qkv, probs, drop) if drop is not None else ctx.save_for_backward(qkv, probs)
-        ctx.heads = int(heads); ctx.has_drop = drop is not None; ctx.bf = bool(batch_first)
         return out
 
     @staticmethod
     def backward(ctx, dout):
+        if ctx.lse:
+            qkv, lse = ctx.saved_tensors
+            (B, S, D3) = qkv.shape if ctx.bf else (qkv.shape[1], qkv.shape[0], qkv.shape[2])
+            g = ops.f32(dout).contiguous()
+            dqkv = torch.empty_like(qkv)
+            delta = torch.empty_like(lse)
+            N.check(N.lib().md_attention_lse_bwd(ops._p(qkv), ops._p(lse), ops._p(g), S, B, D3 // 3, ctx.heads, int(ctx.bf), ops._p(dqkv),
+                                                 ops._p(delta), ops._stream()), "md_attention_lse_bwd")
+            return dqkv, None, None, None, None
         if ctx.has_drop:
             qkv, probs, drop = ctx.saved_tensors
         else:

@@ -312,6 +312,16 @@ int md_attention_fwd(const float* qkv, const float* mask, const float* drop, int
                      int32_t batch_first, float* probs, float* out, void* stream);
 int md_attention_bwd(const float* qkv, const float* probs, const float* drop, const float* dout, int32_t S, int32_t B, int32_t D,
                      int32_t H, int32_t batch_first, float* dqkv, float* ds_scratch /* B*H*S*S floats */, void* stream);
+
+/* The same attention without the S x S matrices (ViViT.py:69-88, unmasked and dropout-free): the forward pass keeps one value per
+ * query row -- lse[B*H][S] = max + log(sum) of its scaled scores -- and the backward pass recomputes the probabilities from q, k and
+ * lse.  md_attention_lse_supported: 1 when the split-precision matrix-core kernels take this shape (S <= 256, d_head 32 or 64, not
+ * in exact-fp32 mode); otherwise use md_attention_fwd / _bwd.  delta: [B*H][S] floats of scratch. */
+int32_t md_attention_lse_supported(int32_t S, int32_t D, int32_t H);
+int md_attention_lse_fwd(const float* qkv, int32_t S, int32_t B, int32_t D, int32_t H, int32_t batch_first, float* lse, float* out,
+                         void* stream);
+int md_attention_lse_bwd(const float* qkv, const float* lse, const float* dout, int32_t S, int32_t B, int32_t D, int32_t H,
+                         int32_t batch_first, float* dqkv, float* delta, void* stream);
 /* ELU (src/models/ViViT.py:166): with dy != NULL the call returns dy * elu'(x).  alpha = 0 is ReLU (MultiModal.py:23,29). */
 int md_elu(const float* x, const float* dy, float alpha, int64_t n, float* out, void* stream);
 int md_gelu(const float* x, const float* dy, int32_t kind, int64_t n, float* out, void* stream);

@@ -310,6 +310,35 @@ __device__ __forceinline__ void at_apply(f32x4 (&o)[DH / 16], const float* pw, i
     }
   }
 }
+// Staged rows as two 16-bit images (hi, lo: [64][DH] halves, row pitch AT_SPB bytes, the lo image AT_SLO bytes after the hi one):
+// split ONCE per workgroup while staging, so the four waves read ready B operands (16 bytes per lane, k = 8 lg .. 8 lg + 7).
+// Same LDS footprint as the fp32 tile (64 x 72 floats).
+#define AT_SPB(DH_) ((DH_) * 2 + 16)
+#define AT_SLO(DH_) (64 * AT_SPB(DH_))
+template <bool F16>
+__device__ __forceinline__ void at_split4(float4 v, uint2& h, uint2& l) {
+  if (F16) {
+    h.x = pk_f16(v.x, v.y); h.y = pk_f16(v.z, v.w);
+    const f16x2 a = __builtin_bit_cast(f16x2, h.x), b = __builtin_bit_cast(f16x2, h.y);
+    l.x = pk_f16(v.x - (float)a[0], v.y - (float)a[1]); l.y = pk_f16(v.z - (float)b[0], v.w - (float)b[1]);
+  } else {
+    h.x = pk_bf16(v.x, v.y); h.y = pk_bf16(v.z, v.w);
+    l.x = pk_bf16(v.x - __builtin_bit_cast(float, h.x << 16), v.y - __builtin_bit_cast(float, h.x & 0xffff0000u));
+    l.y = pk_bf16(v.z - __builtin_bit_cast(float, h.y << 16), v.w - __builtin_bit_cast(float, h.y & 0xffff0000u));
+  }
+}
+template <int DH, bool F16>
+__device__ __forceinline__ void at_commit_split(char* img, const AtRegs<DH>& rg) {
+  constexpr int CH = DH / 4;
+#pragma unroll
+  for (int k = 0; k < 64 * CH / 256; ++k) {
+    const int e = threadIdx.x + 256 * k, r = e / CH, c = e - r * CH;
+    uint2 h, l;
+    at_split4<F16>(rg.v[k], h, l);
+    *(uint2*)(img + r * AT_SPB(DH) + c * 8) = h;
+    *(uint2*)(img + AT_SLO(DH) + r * AT_SPB(DH) + c * 8) = l;
+  }
+}
 // ---- split-precision form of the two products (every fp32 product as three 16-bit MFMAs on hi + lo halves, exactly as in the
 // convolution kernels: fp16 halves in the forward pass, bf16 in the backward pass; v_mfma_f32_16x16x32: 5.3x the rate of the fp32
 // instruction for the same contraction).  The LDS tiles stay fp32; a lane reads the 8 values it feeds to one instruction (k = 8 lg
@@ -334,7 +363,7 @@ __device__ __forceinline__ void at_scores_sp(f32x4 (&acc)[AT_MAXT], const uint4 
   for (int kt = 0; kt < AT_MAXT / 4; ++kt) {
     if (kt * 4 < nt) {
       __syncthreads();
-      at_commit<DH, AT_KP>(tile, rg);
+      at_commit_split<DH, F16>((char*)tile, rg);
       __syncthreads();
       if ((kt + 1) * 4 < nt) at_fetch<DH>(rg, base, width, (kt + 1) * 64, S, B, b, bf);
 #pragma unroll
@@ -342,11 +371,8 @@ __device__ __forceinline__ void at_scores_sp(f32x4 (&acc)[AT_MAXT], const uint4 
         if (kt * 4 + j < nt) {
 #pragma unroll
           for (int s = 0; s < DH / 32; ++s) {
-            const float* p = tile + (16 * j + li) * AT_KP + s * 32 + lg * 8;
-            float v[8];
-            *(float4*)v = *(const float4*)p; *(float4*)(v + 4) = *(const float4*)(p + 4);
-            uint4 bh, bl;
-            at_split8<F16>(v, bh, bl);
+            const char* p = (const char*)tile + (16 * j + li) * AT_SPB(DH) + s * 64 + lg * 16;
+            const uint4 bh = *(const uint4*)p, bl = *(const uint4*)(p + AT_SLO(DH));
             acc[kt * 4 + j] = at_mma3<F16>(ah[s], al[s], bh, bl, acc[kt * 4 + j]);
           }
         }

@@ -339,6 +339,17 @@ __device__ __forceinline__ void at_commit_split(char* img, const AtRegs<DH>& rg)
     *(uint2*)(img + AT_SLO(DH) + r * AT_SPB(DH) + c * 8) = l;
   }
 }
+// Transposing LDS read (ds_read_b64_tr_b16) of a [row][column] 16-bit image: within a 16-lane group, lane 4 lq + lp addresses the
+// 8-byte chunk (columns 4 lp .. 4 lp + 3) of row lq, and receives column (its own index in the group) of rows 0..3.  Two reads give
+// the 8 reduction slots of one v_mfma_f32_16x16x32 operand: slots 0-3 = rows r .. r + 3, slots 4-7 = rows r + 16 .. r + 19.
+typedef short at_s16x4 __attribute__((ext_vector_type(4)));
+typedef short at_s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint4 at_tr2(const char* p0, const char* p1) {
+  const at_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((at_s16x4 __attribute__((address_space(3)))*)p0);
+  const at_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((at_s16x4 __attribute__((address_space(3)))*)p1);
+  at_s16x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(uint4, r);
+}
 // ---- split-precision form of the two products (every fp32 product as three 16-bit MFMAs on hi + lo halves, exactly as in the
 // convolution kernels: fp16 halves in the forward pass, bf16 in the backward pass; v_mfma_f32_16x16x32: 5.3x the rate of the fp32
 // instruction for the same contraction).  The LDS tiles stay fp32; a lane reads the 8 values it feeds to one instruction (k = 8 lg
@@ -385,28 +396,29 @@ __device__ __forceinline__ void at_scores_sp(f32x4 (&acc)[AT_MAXT], const uint4 
 template <int DH, bool F16>
 __device__ __forceinline__ void at_apply_sp(f32x4 (&o)[DH / 16], const float* pw, int pp, float* tile, AtRegs<DH>& rg, cfp base, int width,
                                             int S, int B, int b, int bf, int nt, int li, int lg) {
+  const int lq = li >> 2, lp = li & 3;
 #pragma unroll
   for (int jn = 0; jn < DH / 16; ++jn) o[jn] = (f32x4){0.f, 0.f, 0.f, 0.f};
   for (int kt = 0; kt * 4 < nt; ++kt) {
     __syncthreads();
-    at_commit<DH, AT_VP>(tile, rg);
+    at_commit_split<DH, F16>((char*)tile, rg);
     __syncthreads();
     if ((kt + 1) * 4 < nt) at_fetch<DH>(rg, base, width, (kt + 1) * 64, S, B, b, bf);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       if (kt * 4 + kb * 2 < nt) {
-        const float* pa = pw + li * pp + kt * 64 + kb * 32 + lg * 8;
+        // reduction slots of this 32-key block: lane group lg takes keys 4 lg .. 4 lg + 3 and 16 + 4 lg .. 16 + 4 lg + 3
+        const float* pa = pw + li * pp + kt * 64 + kb * 32 + lg * 4;
         float v[8];
-        *(float4*)v = *(const float4*)pa; *(float4*)(v + 4) = *(const float4*)(pa + 4);
+        *(float4*)v = *(const float4*)pa; *(float4*)(v + 4) = *(const float4*)(pa + 16);
         uint4 ph, pl;
         at_split8<F16>(v, ph, pl);
+        const char* r0 = (const char*)tile + (kb * 32 + lg * 4 + lq) * AT_SPB(DH) + lp * 8;
+        const char* r1 = r0 + 16 * AT_SPB(DH);
 #pragma unroll
         for (int jn = 0; jn < DH / 16; ++jn) {
-          float w[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) w[e] = tile[(kb * 32 + lg * 8 + e) * AT_VP + jn * 16 + li];
-          uint4 vh, vl;
-          at_split8<F16>(w, vh, vl);
+          const uint4 vh = at_tr2(r0 + jn * 32, r1 + jn * 32);
+          const uint4 vl = at_tr2(r0 + AT_SLO(DH) + jn * 32, r1 + AT_SLO(DH) + jn * 32);
           o[jn] = at_mma3<F16>(ph, pl, vh, vl, o[jn]);
         }
       }

@@ -783,10 +783,10 @@ template <int DH>
 __global__ __launch_bounds__(256) void k_attn_lse_bwd_kv(cfp qkv, cfp lse, cfp delta, cfp dout, int S, int B, int D, int H, int bf, float scale,
                                                         float* __restrict__ dqkv) {
   extern __shared__ float sm[];
-  float* tq = sm;                      // 64 x AT_VP
-  float* td = sm + 64 * AT_VP;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
-  float* pT = sm + 2 * 64 * AT_VP + wave * 2 * 16 * AT_TP;
+  float* tq = sm;                      // 64 x AT_VP fp32 (fp16 halves for S^T, bf16 halves for dk: split per use)
+  char* td = (char*)(sm + 64 * AT_VP);  // dO rows as bf16 hi | lo images: natural reads for dP^T, transposing reads for dv
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4, lq = li >> 2, lp = li & 3;
+  float* pT = sm + 64 * AT_VP + 2 * AT_SLO(64) / 4 + wave * 2 * 16 * AT_TP;
   float* dsT = pT + 16 * AT_TP;
   const int bh = blockIdx.x, b = bh / H, h = bh - b * H, nt = (S + 15) >> 4;
   const int j0 = blockIdx.y * 64 + wave * 16;
@@ -812,7 +812,11 @@ __global__ __launch_bounds__(256) void k_attn_lse_bwd_kv(cfp qkv, cfp lse, cfp d
   for (int it = 0; it * 4 < nt; ++it) {
     __syncthreads();
     at_stage<DH, AT_VP>(tq, qkv + h * DH, 3 * D, it * 64, S, B, b, bf);
-    at_stage<DH, AT_VP>(td, dout + h * DH, D, it * 64, S, B, b, bf);
+    {
+      AtRegs<DH> rd;
+      at_fetch<DH>(rd, dout + h * DH, D, it * 64, S, B, b, bf);
+      at_commit_split<DH, false>(td, rd);
+    }
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -822,15 +826,14 @@ __global__ __launch_bounds__(256) void k_attn_lse_bwd_kv(cfp qkv, cfp lse, cfp d
 #pragma unroll
         for (int s = 0; s < DH / 32; ++s) {
           const float* pq = tq + (16 * t + li) * AT_VP + s * 32 + lg * 8;
-          const float* pd = td + (16 * t + li) * AT_VP + s * 32 + lg * 8;
-          float v[8], w[8];
+          const char* pd = td + (16 * t + li) * AT_SPB(DH) + s * 64 + lg * 16;
+          float v[8];
           *(float4*)v = *(const float4*)pq; *(float4*)(v + 4) = *(const float4*)(pq + 4);
-          *(float4*)w = *(const float4*)pd; *(float4*)(w + 4) = *(const float4*)(pd + 4);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] *= scale;
-          uint4 qh, ql, oh, ol;
+          uint4 qh, ql;
           at_split8<true>(v, qh, ql);
-          at_split8<false>(w, oh, ol);
+          const uint4 oh = *(const uint4*)pd, ol = *(const uint4*)(pd + AT_SLO(DH));
           st = at_mma3<true>(kh[s], kl[s], qh, ql, st);
           dp = at_mma3<false>(vh[s], vl[s], oh, ol, dp);
         }
@@ -848,25 +851,26 @@ __global__ __launch_bounds__(256) void k_attn_lse_bwd_kv(cfp qkv, cfp lse, cfp d
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       if (it * 4 + kb * 2 < nt) {
+        // dv: reduction slots in the transposing reads' order (queries 4 lg .. + 3 and 16 + 4 lg .. + 3 of the block); dk: 8 lg .. + 7
         float ap[8], ads[8];
-        const float* pp_ = pT + li * AT_TP + kb * 32 + lg * 8;
+        const float* pp_ = pT + li * AT_TP + kb * 32 + lg * 4;
         const float* pd_ = dsT + li * AT_TP + kb * 32 + lg * 8;
-        *(float4*)ap = *(const float4*)pp_; *(float4*)(ap + 4) = *(const float4*)(pp_ + 4);
+        *(float4*)ap = *(const float4*)pp_; *(float4*)(ap + 4) = *(const float4*)(pp_ + 16);
         *(float4*)ads = *(const float4*)pd_; *(float4*)(ads + 4) = *(const float4*)(pd_ + 4);
         uint4 ph, pl, dsh, dsl;
         at_split8<false>(ap, ph, pl);
         at_split8<false>(ads, dsh, dsl);
+        const char* r0 = td + (kb * 32 + lg * 4 + lq) * AT_SPB(DH) + lp * 8;
+        const char* r1 = r0 + 16 * AT_SPB(DH);
 #pragma unroll
         for (int jn = 0; jn < DH / 16; ++jn) {
-          float wq[8], wd[8];
+          float wq[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            wq[e] = tq[(kb * 32 + lg * 8 + e) * AT_VP + jn * 16 + li];
-            wd[e] = td[(kb * 32 + lg * 8 + e) * AT_VP + jn * 16 + li];
-          }
-          uint4 qh, ql, oh, ol;
+          for (int e = 0; e < 8; ++e) wq[e] = tq[(kb * 32 + lg * 8 + e) * AT_VP + jn * 16 + li];
+          uint4 qh, ql;
           at_split8<false>(wq, qh, ql);
-          at_split8<false>(wd, oh, ol);
+          const uint4 oh = at_tr2(r0 + jn * 32, r1 + jn * 32);
+          const uint4 ol = at_tr2(r0 + AT_SLO(DH) + jn * 32, r1 + AT_SLO(DH) + jn * 32);
           dk[jn] = at_mma3<false>(dsh, dsl, qh, ql, dk[jn]);
           dv[jn] = at_mma3<false>(ph, pl, oh, ol, dv[jn]);
         }
@@ -1092,7 +1096,7 @@ extern "C" int md_attention_lse_bwd(const float* qkv, const float* lse, const fl
   if (!md_attention_lse_supported(S, D, H)) return MD_ERR_UNSUPPORTED;
   if (!attn_mfma_prepare()) return MD_ERR_LAUNCH;
   const dim3 grid(B * H, md_cdiv(S, 64));
-  const size_t la = attn_mfma_lds(S, true), lb = (size_t)(2 * 64 * AT_VP + 4 * 2 * 16 * AT_TP) * 4;
+  const size_t la = attn_mfma_lds(S, true), lb = (size_t)(64 * AT_VP + 4 * 2 * 16 * AT_TP) * 4 + 2 * AT_SLO(64);
   const float sc = 1.f / sqrtf((float)(D / H));
   const int bf = batch_first ? 1 : 0, pp = attn_pp(S, true);
   hipStream_t st = (hipStream_t)stream;

@@ -253,15 +253,6 @@ __device__ __forceinline__ void at_fetch(AtRegs<DH>& rg, cfp base, int width, in
     rg.v[k] = v;
   }
 }
-template <int DH, int P>
-__device__ __forceinline__ void at_commit(float* tile, const AtRegs<DH>& rg) {
-  constexpr int CH = DH / 4;
-#pragma unroll
-  for (int k = 0; k < 64 * CH / 256; ++k) {
-    const int e = threadIdx.x + 256 * k, r = e / CH, c = e - r * CH;
-    *(float4*)(tile + r * P + c * 4) = rg.v[k];
-  }
-}
 // acc[t] (t < nt) = afrag (16 x DH) . rows^T for the rows of `base` (staged 64 at a time)
 template <int DH>
 __device__ __forceinline__ void at_scores(f32x4 (&acc)[AT_MAXT], const f32x4 (&a)[DH / 16], float* tile, cfp base, int width, int S,

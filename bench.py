@@ -27,6 +27,9 @@ for p in (ROOT, PKG):
 # queue and stall it at every stage boundary (6.54 ms per step against 6.29 with 2, 6, 8, 12 or 16 queues; the single-process
 # step does not care).  Must be set before the runtime initialises, i.e. before the first HIP call.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Kernel arguments in device memory (the runtime's default on this image; stated here because the step is a chain of ~290 dependent
+# launches and host-memory kernargs cost 0.5 ms of it: HIP_FORCE_DEV_KERNARG=0 measured 6.68 ms against 6.15).
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

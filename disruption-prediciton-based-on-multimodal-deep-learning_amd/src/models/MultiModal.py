@@ -118,8 +118,8 @@ class MultiModalModel_GB(nn.Module):
     def _both(self, x_vis, x_ts):
         vis_latent = self.vis_model._encode(x_vis)
         ts_latent = self.ts_model.encoder(x_ts)
-        self.vis_latent = (vis_latent,)
-        self.ts_latent = (ts_latent,)
+        self.vis_latent = (vis_latent.detach(),)       # values only: a kept graph would outlive the step (src/utils/graphed.py)
+        self.ts_latent = (ts_latent.detach(),)
         return vis_latent, ts_latent
 
     def forward(self, x_vis: torch.Tensor, x_ts: torch.Tensor):
@@ -219,8 +219,8 @@ class TFN_GB(nn.Module):
         vis, ts = self.embedd_subnet['network_video'], self.embedd_subnet['network_0D']
         h_vis = vis._encode(x_vis)
         h_0D = ts.encoder(x_0D)
-        self.h_vis = (h_vis,)
-        self.h_0D = (h_0D,)
+        self.h_vis = (h_vis.detach(),)                 # values only (see vis_latent)
+        self.h_0D = (h_0D.detach(),)
         out_vis = vis._head(h_vis)
         out_0D = ts._head(h_0D)
         fusion = dropout(OuterFusionFunction.apply(h_vis, h_0D), self.dropout.p, self.dropout.training)

@@ -90,8 +90,8 @@ class FusionGB(nn.Module):
             vis_latent = self._vis[0](x_vis)
             ts_latent, out_ts = self._ts_branch(x_ts)
             out_vis = self._vis[1](vis_latent)
-        self.vis_latent = (vis_latent,)
-        self.ts_latent = (ts_latent,)
+        self.vis_latent = (vis_latent.detach(),)       # values only: a kept graph would outlive the step (src/utils/graphed.py)
+        self.ts_latent = (ts_latent.detach(),)
         x = _connector(torch.cat([vis_latent, ts_latent], axis=1), self.connector)
         out_multi = _classifier(x, self.classifier)
         return out_multi if self.use_stream == 'multi' else (out_multi, out_vis, out_ts)

@@ -34,6 +34,8 @@ class GraphedStep:
             mod.__dict__.pop("_static", None)              # (one live GraphedStep per model: a new one brings its own staging buffer)
         self.model, self.loss_fn = model, loss_fn
         self._done = torch.cuda.Event()
+        from . import streams
+        streams.prepare(example_inputs[0].device)         # the branch streams exist before the capture opens
         self.inputs = [t.detach().clone() for t in example_inputs]
         self.target = example_target.detach().clone()
         import warnings

@@ -3,26 +3,42 @@ SlowFast between two lateral connections, the video and the 0D encoder of a fusi
 about 1100 launches of 9 us on average per step), so one stream leaves most of the 256 CUs idle; on separate streams the branches
 overlap, and a captured step (``src/utils/graphed.py``) keeps that overlap as parallel graph branches.  Autograd runs every
 backward node on the stream its forward ran on and orders the streams itself, so only the forward needs the fork/join here.
-``MD_STREAMS=0`` keeps everything on the current stream (same results: the kernels and their order per tensor are unchanged).
+Default: only inside a stream capture (``MD_STREAMS=1`` always, ``MD_STREAMS=0`` never; same results either way: the kernels and
+their order per tensor are unchanged).
 """
 import os
 from typing import Dict, Iterable, Tuple
 
 import torch
 
-_ENABLED = os.environ.get("MD_STREAMS") != "0"
+# MD_STREAMS=1: always; MD_STREAMS=0: never; unset (None): only while a stream capture is open.  Eager, the composable models are
+# host-bound (the GPU waits for Python), so overlapping branches buys nothing there and the extra event / record_stream calls cost
+# host time (cfg4 eager 11.1 -> 12.0 ms with the streams on); inside a capture the same forks become parallel graph branches.
+_ENABLED = {"1": True, "0": False}.get(os.environ.get("MD_STREAMS"), None)
 # a unit's weight gradient on a helper stream beside its data gradient: bit-identical, measured SLOWER in the captured cfg5 step
 # (8.9 ms against 7.4 ms with the pathway streams alone: every fork/join is a cross-stream edge the graph pays for), so off
 _UNIT_HELPERS = os.environ.get("MD_STREAMS_WGRAD") == "1"
 _SIDE: Dict[Tuple[int, int], "torch.cuda.Stream"] = {}
 
 
+def prepare(device=None) -> None:
+    """Create the side streams of ``device`` now (GraphedStep calls this before its warm-up: nothing is created inside a capture)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    for k in (0, 1):
+        side_stream(dev, k)
+
+
 def enabled(t: torch.Tensor) -> bool:
-    return _ENABLED and t.is_cuda
+    if _ENABLED is False or not t.is_cuda:
+        return False
+    if _ENABLED:
+        return True
+    dev = t.device.index if t.device.index is not None else torch.cuda.current_device()
+    return (dev, 0) in _SIDE and (dev, 1) in _SIDE and torch.cuda.is_current_stream_capturing()
 
 
 def unit_helpers(t: torch.Tensor) -> bool:
-    return _ENABLED and _UNIT_HELPERS and t.is_cuda
+    return _UNIT_HELPERS and enabled(t)
 
 
 def side_stream(device: torch.device, k: int = 0) -> "torch.cuda.Stream":

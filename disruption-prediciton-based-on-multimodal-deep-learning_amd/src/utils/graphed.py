@@ -147,7 +147,40 @@ class GraphedBranch:
         wrap = GraphedBranch._Wrap(owner, fn)
         wrap.train(owner.training)
         samples = tuple(t.detach().clone() for t in example_inputs)
+        self._refuse_stale_graphs(owner, wrap, samples)
         self.call = torch.cuda.make_graphed_callables(wrap, samples)
+
+    @staticmethod
+    def _refuse_stale_graphs(owner, wrap, samples):
+        """One eager forward + backward of the branch on a side stream, listening for PyTorch's AccumulateGrad stream-mismatch warning
+        (see GraphedStep): an autograd graph of an earlier step that is still alive would make the capture below synchronise with
+        the stream that graph ran on, and ROCm 7.2 crashes in hipStreamEndCapture instead of reporting it.  Parameter gradients are
+        put back afterwards."""
+        import warnings
+        params = [p for p in owner.parameters() if p.requires_grad]
+        kept = [p.grad for p in params]
+        for p in params:
+            p.grad = None
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        warn_always = torch.is_warn_always_enabled()
+        torch.set_warn_always(True)
+        try:
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                with torch.cuda.stream(side):
+                    out = wrap(*samples)
+                    outs = [o for o in (out if isinstance(out, tuple) else (out,)) if o.requires_grad]
+                    torch.autograd.backward(outs, [torch.zeros_like(o) for o in outs])
+                    del out, outs
+        finally:
+            torch.set_warn_always(warn_always)
+            torch.cuda.current_stream().wait_stream(side)
+            for p, g in zip(params, kept):
+                p.grad = g
+        if any("AccumulateGrad node's stream does not match" in str(w.message) for w in caught):
+            raise RuntimeError("GraphedBranch: an autograd graph from an earlier step is still alive (a kept loss / output tensor); "
+                               "delete or .detach() it before the branch is captured")
 
     def matches(self, inputs: Sequence[torch.Tensor], training: bool) -> bool:
         return training == self.training and tuple(tuple(t.shape) for t in inputs) == self.shapes

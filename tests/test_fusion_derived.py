@@ -255,3 +255,29 @@ def test_graphed_0d_branch_matches_the_eager_step():
         assert g0.keys() == g1.keys()
         for k in g0:
             assert torch.equal(g0[k], g1[k]), k
+
+
+@pytest.mark.gpu
+def test_graphed_0d_branch_refuses_a_stale_autograd_graph():
+    """An eager step on the default stream whose loss tensor is kept alive, then MD_GRAPH_BRANCH: the capture would have to
+    synchronise with the default stream (ROCm 7.2 crashes in hipStreamEndCapture); GraphedBranch notices the stale graph in its eager
+    probe, FusionGB says so and stays eager -- the step still runs."""
+    import src.models.fusion as fu
+    torch.manual_seed(22)
+    m = _native("cfg4").cuda().train()
+    xv, xt = torch.randn(4, 3, 5, 24, 24, device="cuda"), torch.randn(4, 5, 6, device="cuda")
+    kept = sum(o.square().sum() for o in m(xv, xt))          # autograd graph alive, built on the default stream
+    kept.backward(retain_graph=True)
+    old = fu._GRAPH_BRANCH
+    fu._GRAPH_BRANCH = True
+    try:
+        for p in m.parameters():
+            p.grad = None
+        outs = m(xv, xt)
+        assert m.__dict__.get("_md_ts_graph") is False         # refused, not crashed
+        sum(o.square().sum() for o in outs).backward()
+        assert all(bool(torch.isfinite(p.grad).all()) for p in m.parameters() if p.grad is not None)
+    finally:
+        fu._GRAPH_BRANCH = old
+        m.__dict__.pop("_md_ts_graph", None)
+    del kept

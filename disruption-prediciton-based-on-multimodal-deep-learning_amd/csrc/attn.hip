@@ -919,19 +919,22 @@ static bool attn_split(int dh) {
 
 // GELU.  kind 0: exact, 0.5 x (1 + erf(x / sqrt 2)) (nn.GELU, transformer.py:85); kind 1: the reference's own tanh form
 // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) (transformer.py:36-38).  bwd: dx = dy * gelu'(x).
+__device__ __forceinline__ void gelu_val(float v, int kind, float& y, float& d) {
+#pragma clang fp contract(off)      // every fused multiply-add is written out: k_gelu and k_bias_gelu_drop then round identically
+  if (kind == 0) {
+    const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
+    y = v * cdf; d = fmaf(v * 0.3989422804014327f, expf(-0.5f * v * v), cdf);
+  } else {
+    const float c = 0.7978845608028654f, u = c * fmaf(0.044715f * v * v, v, v), th = tanhf(u);
+    y = 0.5f * v * (1.f + th);
+    d = fmaf(0.5f * v * (1.f - th * th) * c, fmaf(3.f * 0.044715f * v, v, 1.f), 0.5f * (1.f + th));
+  }
+}
 __global__ __launch_bounds__(256) void k_gelu(const float* __restrict__ x, const float* __restrict__ dy, int kind, int64_t n,
                                              float* __restrict__ out) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float v = x[i];
     float y, d;
-    if (kind == 0) {
-      const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
-      y = v * cdf; d = cdf + v * 0.3989422804014327f * expf(-0.5f * v * v);
-    } else {
-      const float c = 0.7978845608028654f, u = c * (v + 0.044715f * v * v * v), th = tanhf(u);
-      y = 0.5f * v * (1.f + th);
-      d = 0.5f * (1.f + th) + 0.5f * v * (1.f - th * th) * c * (1.f + 3.f * 0.044715f * v * v);
-    }
+    gelu_val(x[i], kind, y, d);
     out[i] = dy ? dy[i] * d : y;
   }
 }
@@ -1153,6 +1156,43 @@ extern "C" int md_attention_bwd(const float* qkv, const float* probs, const floa
   MD_CHECK_LAUNCH();
   return MD_OK;
 }
+// Linear bias + GELU + inverted dropout of a FeedForward's hidden activation in ONE pass each way (ViViT.py:31-46, transformer.py:85):
+// h = x + bias[c], y = gelu(h), out = y * mask * scale (mask == nullptr: no dropout) -- the same arithmetic, in the same order, as
+// md_channel_bias_fwd -> md_gelu -> md_mask_scale, so results are bit-identical to the three passes (68 MB each way per pass at cfg3).
+// Backward: dx = dout * mask * scale * gelu'(x + bias); the bias gradient is the column sum of dx (md_channel_bias_bwd).
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_bias_gelu_drop(const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ mask,
+                                                       const float* __restrict__ dout, float scale, int kind, int64_t n4, int c4,
+                                                       float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 a = ((const float4*)x)[i], b = ((const float4*)bias)[i % c4];
+    const float h[4] = {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
+    float m[4] = {1.f, 1.f, 1.f, 1.f}, g[4] = {0.f, 0.f, 0.f, 0.f}, r[4];
+    if (mask) { const float4 mm = ((const float4*)mask)[i]; m[0] = mm.x; m[1] = mm.y; m[2] = mm.z; m[3] = mm.w; }
+    if (BWD) { const float4 gg = ((const float4*)dout)[i]; g[0] = gg.x; g[1] = gg.y; g[2] = gg.z; g[3] = gg.w; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float y, d;
+      gelu_val(h[e], kind, y, d);
+      if (BWD) r[e] = (mask ? g[e] * m[e] * scale : g[e]) * d;
+      else r[e] = mask ? y * m[e] * scale : y;
+    }
+    ((float4*)out)[i] = make_float4(r[0], r[1], r[2], r[3]);
+  }
+}
+extern "C" int md_bias_gelu_drop(const float* x, const float* bias, const float* mask, const float* dout, float scale, int32_t kind,
+                                 int64_t rows, int32_t C, float* out, void* stream) {
+  if (!x || !bias || !out) return MD_ERR_NULL;
+  if (rows <= 0 || C <= 0 || (C & 3) || (kind != 0 && kind != 1)) return MD_ERR_BAD_SHAPE;
+  if ((((uintptr_t)x | (uintptr_t)bias | (uintptr_t)mask | (uintptr_t)dout | (uintptr_t)out) & 15) != 0) return MD_ERR_BAD_SHAPE;
+  const int64_t n4 = rows * (C / 4);
+  int64_t blocks = (n4 + 255) / 256; if (blocks > 8192) blocks = 8192;
+  if (dout) MD_KLAUNCH(k_bias_gelu_drop<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, bias, mask, dout, scale, kind, n4, C / 4, out);
+  else MD_KLAUNCH(k_bias_gelu_drop<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, bias, mask, dout, scale, kind, n4, C / 4, out);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+
 extern "C" int md_gelu(const float* x, const float* dy, int32_t kind, int64_t n, float* out, void* stream) {
   if (!x || !out) return MD_ERR_NULL;
   if (n <= 0 || (kind != 0 && kind != 1)) return MD_ERR_BAD_SHAPE;

@@ -136,6 +136,7 @@ SIGNATURES = {
     "md_outer_fwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P]),
     "md_outer_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _P, _P, _P]),
     "md_gelu": (C.c_int, [_P, _P, _I32, C.c_int64, _P, _P]),
+    "md_bias_gelu_drop": (C.c_int, [_P, _P, _P, _P, C.c_float, _I32, _I64, _I32, _P, _P]),
     "md_lstm_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P]),
     "md_lstm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P]),
     "md_opt_chunk_elems": (C.c_int, []),

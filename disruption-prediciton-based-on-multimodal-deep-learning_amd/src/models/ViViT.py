@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from ._unit import (AddLayerNormFunction, AttentionFunction, EluFunction, GeluFunction, PatchEmbedFunction, ResidualLayerNormFunction,
-                    _ChannelBias, _SeqSum, dropout, linear_wb)
+                    _ChannelBias, _SeqSum, dropout, linear_bias_gelu_dropout, linear_wb)
 
 
 def _layer_norm(x, norm: nn.LayerNorm):
@@ -69,8 +69,9 @@ class FeedForward(nn.Module):
         )
 
     def forward(self, x: torch.Tensor):
-        h = GeluFunction.apply(_rows(x, self.net[0]), 0)
-        h = dropout(h, self.net[2].p, self.net[2].training)
+        lin = self.net[0]
+        h = linear_bias_gelu_dropout(x.reshape(-1, x.shape[-1]), lin.weight, lin.bias, self.net[2].p, self.net[2].training, 0)
+        h = h.reshape(x.shape[:-1] + (lin.out_features,))
         return dropout(_rows(h, self.net[3]), self.net[4].p, self.net[4].training)
 
 

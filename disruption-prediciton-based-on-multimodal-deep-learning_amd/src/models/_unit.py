@@ -829,6 +829,53 @@ class GeluFunction(torch.autograd.Function):
         return dx, None
 
 
+class BiasGeluDropFunction(torch.autograd.Function):
+    """gelu(x + bias) * mask * scale over rows (md_bias_gelu_drop): the three elementwise passes between a FeedForward's two Linears
+    in one, bit-identical to them.  mask None: no dropout."""
+
+    @staticmethod
+    def forward(ctx, x, bias, mask, scale, kind):
+        x = ops.f32(x).contiguous(); bias = ops.f32(bias).contiguous()
+        ops.require_cuda(x, bias, mask)
+        rows, Cc = x.shape
+        out = torch.empty_like(x)
+        N.check(N.lib().md_bias_gelu_drop(ops._p(x), ops._p(bias), ops._p(mask), None, float(scale), int(kind), rows, Cc, ops._p(out),
+                                          ops._stream()), "md_bias_gelu_drop")
+        ctx.save_for_backward(x, bias) if mask is None else ctx.save_for_backward(x, bias, mask)
+        ctx.scale, ctx.kind, ctx.has_mask = float(scale), int(kind), mask is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if ctx.has_mask:
+            x, bias, mask = ctx.saved_tensors
+        else:
+            (x, bias), mask = ctx.saved_tensors, None
+        g = ops.f32(dout).contiguous()
+        rows, Cc = x.shape
+        dx = torch.empty_like(x)
+        N.check(N.lib().md_bias_gelu_drop(ops._p(x), ops._p(bias), ops._p(mask), ops._p(g), ctx.scale, ctx.kind, rows, Cc, ops._p(dx),
+                                          ops._stream()), "md_bias_gelu_drop")
+        db = torch.empty(Cc, device=g.device)
+        ns = N.lib().md_channel_bias_bwd_scratch_floats(rows, Cc, 1)
+        scratch = torch.empty(ns, device=g.device) if ns else None
+        N.check(N.lib().md_channel_bias_bwd(ops._p(dx), rows, Cc, 1, ops._p(db), ops._p(scratch), ops._stream()), "md_channel_bias_bwd")
+        return dx, db, None, None, None
+
+
+def linear_bias_gelu_dropout(x2d, weight, bias, p: float, training: bool, kind: int = 0):
+    """dropout(gelu(x @ weight^T + bias)): the MFMA Linear, then one fused elementwise pass (three separately when the width is not a
+    multiple of 4 or the Linear has no bias)."""
+    y = LinearRowsFunction.apply(x2d, weight)
+    if bias is None or y.shape[1] % 4:
+        return dropout(GeluFunction.apply(y if bias is None else _ChannelBias.apply(y.contiguous()[:, :, None], bias)[:, :, 0], kind), p, training)
+    y = y.contiguous()
+    if training and p > 0.0:
+        keep = 1.0 - p
+        return BiasGeluDropFunction.apply(y, bias, torch.empty_like(y).bernoulli_(keep), 1.0 / keep, kind)
+    return BiasGeluDropFunction.apply(y, bias, None, 1.0, kind)
+
+
 def linear_wb(x2d, weight, bias):
     """x (rows, D_in) @ weight(D_out, D_in)^T + bias: the rows-major 1x1x1 convolution plus the per-channel bias kernel."""
     y = LinearRowsFunction.apply(x2d, weight)

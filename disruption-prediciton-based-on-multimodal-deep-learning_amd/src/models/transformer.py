@@ -18,7 +18,7 @@ from .. import _native as N
 from .. import ops
 from .NoiseLayer import NoiseLayer
 from ._unit import (AddLayerNormFunction, AttentionFunction, ConvFunction, GeluFunction, _ChannelBias, _SeqSum, conv1d_bn_leaky,
-                    dropout, linear, linear_wb)
+                    dropout, linear, linear_bias_gelu_dropout, linear_wb)
 
 
 class PositionalEncoding(nn.Module):
@@ -81,8 +81,8 @@ class TransformerEncoder(nn.Module):
         att = AttentionFunction.apply(qkv, mask, sa.num_heads, drop)
         att = linear_wb(att.view(S * B, D), sa.out_proj.weight, sa.out_proj.bias).view(S, B, D)
         x = AddLayerNormFunction.apply(x, dropout(att, layer.dropout1.p, tr), layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
-        h = GeluFunction.apply(linear_wb(x.view(S * B, D), layer.linear1.weight, layer.linear1.bias), 1)
-        h = linear_wb(dropout(h, layer.dropout.p, tr), layer.linear2.weight, layer.linear2.bias).view(S, B, D)
+        h = linear_bias_gelu_dropout(x.view(S * B, D), layer.linear1.weight, layer.linear1.bias, layer.dropout.p, tr, 1)
+        h = linear_wb(h, layer.linear2.weight, layer.linear2.bias).view(S, B, D)
         return AddLayerNormFunction.apply(x, dropout(h, layer.dropout2.p, tr), layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
 
     def _filter(self, x_bft):

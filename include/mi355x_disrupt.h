@@ -325,6 +325,13 @@ int md_attention_lse_bwd(const float* qkv, const float* lse, const float* dout, 
 /* ELU (src/models/ViViT.py:166): with dy != NULL the call returns dy * elu'(x).  alpha = 0 is ReLU (MultiModal.py:23,29). */
 int md_elu(const float* x, const float* dy, float alpha, int64_t n, float* out, void* stream);
 int md_gelu(const float* x, const float* dy, int32_t kind, int64_t n, float* out, void* stream);
+
+/* FeedForward hidden activation in one pass (ViViT.py:31-46: Linear bias -> nn.GELU -> nn.Dropout): out = gelu(x + bias[c]) * mask *
+ * scale over x[rows][C] (C % 4 == 0, 16-byte aligned pointers; mask NULL: no dropout; kind as md_gelu).  With dout: the backward,
+ * out = dout * mask * scale * gelu'(x + bias); the bias gradient is its column sum (md_channel_bias_bwd).  Bit-identical to
+ * md_channel_bias_fwd -> md_gelu -> md_mask_scale. */
+int md_bias_gelu_drop(const float* x, const float* bias, const float* mask, const float* dout, float scale, int32_t kind, int64_t rows,
+                      int32_t C, float* out, void* stream);
 /* Device-side tail of DatasetForVideo.get_video_data (src/dataset.py:124-144, without the cv2 augmentations): centre crop of
  * S x S (rows Hr/2 - S/2 .., columns Wr/2 - S/2 .., :241-246; S even), subtraction of the BGR means (:203-207, host array of 3)
  * and the (T,H,W,C) -> (C,T,H,W) transpose (:229-230) from uint8 frames [B][T][Hr][Wr][3].  layout 0: out [B][3][T][S][S];

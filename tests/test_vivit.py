@@ -241,3 +241,24 @@ def test_fused_patch_embedding_matches_fp64(b, t, c, S, p, dim, perm):
     for name, a, r in (("w", wg.grad, w64.grad), ("bias", bg.grad, b64.grad), ("pos", pg.grad, p64.grad), ("token", tg.grad, t64.grad),
                        ("x", xg.grad, gx64)):
         assert rel(a, r) < 3e-5, (name, rel(a, r))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,use_mask", [(0, True), (0, False), (1, True)])
+def test_fused_bias_gelu_dropout_is_bit_identical_to_the_three_passes(kind, use_mask):
+    """md_bias_gelu_drop (the FeedForward's hidden activation in one pass each way) against md_channel_bias_fwd -> md_gelu ->
+    md_mask_scale and their backward passes: same arithmetic in the same order, so outputs, input gradient and bias gradient agree
+    bit for bit."""
+    from src.models._unit import BiasGeluDropFunction, GeluFunction, _ChannelBias, _MaskScale
+    g = torch.Generator().manual_seed(31 + kind)
+    x = torch.randn(777, 1024, generator=g).cuda(); b = torch.randn(1024, generator=g).cuda()
+    mask = (torch.rand(777, 1024, generator=g) > 0.1).float().cuda() if use_mask else None
+    dout = torch.randn(777, 1024, generator=g).cuda()
+    x1, b1 = x.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y1 = BiasGeluDropFunction.apply(x1, b1, mask, 1.0 / 0.9, kind)
+    y1.backward(dout)
+    x2, b2 = x.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    h = GeluFunction.apply(_ChannelBias.apply(x2[:, :, None], b2)[:, :, 0], kind)
+    y2 = _MaskScale.apply(h, mask, 1.0 / 0.9) if use_mask else h
+    y2.backward(dout)
+    assert torch.equal(y1, y2) and torch.equal(x1.grad, x2.grad) and torch.equal(b1.grad, b2.grad)

@@ -1445,6 +1445,15 @@ static bool wgrad_build(const MdConvDesc* d, WGeom* out, size_t* lds_bytes, int*
   return true;
 }
 
+static bool wgrad_use_pf(const WGeom& g);
+// Few k-tiles (<= 8: a Linear with 128 input channels, a 3-tap convolution over 32) on the non-prefetching kernel: two k-tiles per
+// wave instead of three (4 waves x 3 = 12 slots for 8 tiles left a third of the MFMAs multiplying padding).  The prefetching
+// kernel interleaves its 12 load groups with 4 x KTW >= 12 MFMA groups and keeps KTW >= 3.
+static void wgrad_narrow_k(WGeom* g) {
+  static const int off = getenv("MD_WGRAD_KTW2") && atoi(getenv("MD_WGRAD_KTW2")) == 0;
+  if (!off && !wgrad_use_pf(*g) && md_cdiv(g->nkt, 4) <= 2) { g->ktw = 2; g->nkg = md_cdiv(g->nkt, 8); }
+}
+
 static bool wgrad_use_pf(const WGeom& g) {
   static const int no_pf = getenv("MD_WGRAD_PF") && atoi(getenv("MD_WGRAD_PF")) == 0;
   static const int dbg = getenv("MD_DBG") ? atoi(getenv("MD_DBG")) : 0;
@@ -1466,7 +1475,8 @@ static const void* wgrad_kernel_nr(int nrep, bool pf) {
 // Workgroups of this kernel that fit on one CU (registers and LDS); 2 when the runtime cannot say (no device).
 static int wgrad_wgs_per_cu(const WGeom& g, size_t lds) {
   const bool pf = wgrad_use_pf(g);
-  const void* k = g.ktw == 3 ? wgrad_kernel_nr<3>(g.nrep, pf) : g.ktw == 4 ? wgrad_kernel_nr<4>(g.nrep, pf) : wgrad_kernel_nr<5>(g.nrep, pf);
+  const void* k = g.ktw == 2 ? wgrad_kernel_nr<2>(g.nrep, false)
+                  : g.ktw == 3 ? wgrad_kernel_nr<3>(g.nrep, pf) : g.ktw == 4 ? wgrad_kernel_nr<4>(g.nrep, pf) : wgrad_kernel_nr<5>(g.nrep, pf);
   int nb = 0;
   if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
       hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 256, lds) != hipSuccess || nb < 1) {
@@ -1492,6 +1502,7 @@ const WgradPlan* wgrad_lookup(const MdConvDesc* d, int xpitch, int xc0, int dw_c
   WgradPlan* wp = nullptr;
   WGeom g; size_t lds = 0; int ns = 0;
   if (wgrad_build(d, &g, &lds, &ns, xpitch, xc0, dw_cin)) {
+    wgrad_narrow_k(&g);
     // one slice (= one slab of partial sums) per resident workgroup: a single full round on the chip, and no more
     // slab traffic than that needs
     // CUs to occupy.  The executor runs weight gradients on a side stream next to the BatchNorm-backward / data-gradient
@@ -1566,7 +1577,7 @@ int wgrad_patch_launch(const WgradPlan* p, const MdConvDesc* d, const float* src
     case 4: LAUNCH_WG(KT_, 4); break;                                                                                   \
     default: LAUNCH_WG(KT_, 5); break;                                                                                  \
   }
-  if (g.ktw == 3) { LAUNCH_WG_NR(3); } else if (g.ktw == 4) { LAUNCH_WG_NR(4); } else { LAUNCH_WG_NR(5); }
+  if (g.ktw == 2) { LAUNCH_WG_NR(2); } else if (g.ktw == 3) { LAUNCH_WG_NR(3); } else if (g.ktw == 4) { LAUNCH_WG_NR(4); } else { LAUNCH_WG_NR(5); }
   MD_CHECK_LAUNCH();
   const int total = g.nkt * 16 * g.N16;
   MD_KLAUNCH(k_wgrad_reduce, dim3(md_cdiv(total, 64)), dim3(256), 0, s, slab, p->nslices, g.nkt, g.KT, g.N16, d->Cout,

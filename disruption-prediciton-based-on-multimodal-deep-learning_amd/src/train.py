@@ -211,10 +211,26 @@ def valid_per_epoch(
     correct = None
     total_pred, total_label = [], []
     total_size = 0
+    graph_ok = _GRAPH_STEPS and torch.device(device).type == "cuda"
+    full_shape = None            # graph mode: the first batch's shape is the one that is captured (the short last batch runs eagerly)
     for batch_idx, (data, target) in enumerate(valid_loader):
         with torch.no_grad():
             optimizer.zero_grad()
-            output, output_vis, output_ts = _forward(model, data, device, model_type)
+            out = None
+            if graph_ok:
+                inputs = [data.to(device)] if model_type == "single" else [data['video'].to(device), data['0D'].to(device)]
+                shape = tuple(tuple(t.shape) for t in inputs)
+                full_shape = shape if full_shape is None else full_shape
+                if shape == full_shape:
+                    from .utils.graphed import graphed_forward
+                    out = graphed_forward(model, inputs, "_md_graphed_eval")
+                    out = tuple(o.clone() for o in out) if isinstance(out, tuple) else out.clone()      # (static tensors of the graph)
+            if out is None:
+                output, output_vis, output_ts = _forward(model, data, device, model_type)
+            elif model_type == "multi-GB":
+                output, output_vis, output_ts = out
+            else:
+                output, output_vis, output_ts = out, None, None
             tgt = target.to(device)
             if model_type == 'multi-GB':
                 loss = loss_fn(output, output_vis, output_ts, tgt)

@@ -119,6 +119,58 @@ class GraphedStep:
         return self.outputs, self.loss
 
 
+class GraphedForward:
+    """Inference forward of a model (``torch.no_grad()``, the module's current train/eval mode) replayed from one HIP graph: the
+    evaluation loops and the sliding-window probability curves of the launch-bound models issue the same few hundred launches for
+    every batch.  ``__call__(inputs)`` copies the batch into static buffers and returns the static outputs (valid until the next
+    call).  Fixed shapes; the caller falls back to the eager forward for any other shape."""
+
+    def __init__(self, model: torch.nn.Module, example_inputs: Sequence[torch.Tensor], warmup: int = 2):
+        from . import streams
+        streams.prepare(example_inputs[0].device)
+        self.model = model
+        self.training = model.training
+        self.shapes = tuple((tuple(t.shape), t.dtype) for t in example_inputs)
+        self.inputs = [t.detach().clone() for t in example_inputs]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.no_grad():
+            with torch.cuda.stream(side):
+                for _ in range(max(1, warmup)):
+                    model(*self.inputs)
+            torch.cuda.current_stream().wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.outputs = model(*self.inputs)
+
+    def matches(self, inputs: Sequence[torch.Tensor]) -> bool:
+        return self.model.training == self.training and tuple((tuple(t.shape), t.dtype) for t in inputs) == self.shapes
+
+    def __call__(self, inputs: Sequence[torch.Tensor]):
+        for dst, src in zip(self.inputs, inputs):
+            dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.outputs
+
+
+def graphed_forward(model: torch.nn.Module, inputs: Sequence[torch.Tensor], slot: str = "_md_graphed_fwd"):
+    """model(*inputs) under no_grad through a cached GraphedForward (one per model, re-captured when the shapes or the mode change);
+    the plain forward when the capture is refused."""
+    gf = model.__dict__.get(slot)
+    if gf is None or (gf is not False and not gf.matches(inputs)):
+        model.__dict__.pop(slot, None)
+        try:
+            gf = GraphedForward(model, inputs)
+        except RuntimeError as e:
+            print("graphed_forward | capture refused, running eagerly (%s)" % str(e).split("\n")[0][:200])
+            gf = False
+        model.__dict__[slot] = gf
+    if gf is False:
+        with torch.no_grad():
+            return model(*inputs)
+    return gf(inputs)
+
+
 class GraphedBranch:
     """One branch of a model (a callable over tensors that owns parameters, e.g. the 0D encoder + its head of a fusion model) with
     its forward and its backward each replayed from a HIP graph, inside an otherwise eager step: ``torch.cuda.make_graphed_callables``

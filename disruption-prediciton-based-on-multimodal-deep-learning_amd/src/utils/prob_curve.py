@@ -23,7 +23,12 @@ import numpy as np
 import torch
 
 from .. import ops
+import os
+
 from .clip_preprocess import preprocess_clips
+from .graphed import graphed_forward
+
+_GRAPH = os.environ.get("MD_GRAPH_STEP") == "1"
 
 FPS = 210
 
@@ -84,7 +89,10 @@ def video_window_probabilities(model: torch.nn.Module, frames: torch.Tensor, seq
             else:
                 idx = (torch.arange(at, at + m, device=frames.device).view(-1, 1) + steps.view(1, -1)).clamp_(max=last)
                 clip = sub[idx]                                                        # (m, seq_len, H, W, 3) uint8 gather
-            _softmax_columns(model(preprocess_clips(clip, crop_size)), p0, cls, at)
+            x = preprocess_clips(clip, crop_size)
+            # MD_GRAPH_STEP=1: the forward of every full batch of windows replayed from one HIP graph (src/utils/graphed.py)
+            out = graphed_forward(model, [x], "_md_graphed_curve") if (_GRAPH and m == W) else model(x)
+            _softmax_columns(out, p0, cls, at)
     return p0.cpu().numpy(), cls.cpu().numpy()
 
 

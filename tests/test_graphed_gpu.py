@@ -8,6 +8,8 @@ import os
 import runpy
 import sys
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -156,3 +158,48 @@ def test_eager_step_of_another_batch_size_leaves_the_captured_noise_buffer_alone
     for k, p in m.named_parameters():
         assert torch.equal(p.grad, grads_g[k]), k
     del loss_e
+
+
+@pytest.mark.gpu
+def test_validation_loop_and_window_curve_with_graph_replay_match_eager():
+    """MD_GRAPH_STEP=1 in the inference paths: valid_per_epoch replays the forward of every full-size batch (GraphedForward) and
+    video_window_probabilities every full batch of windows -- same kernels on the same bytes, so losses / accuracies / F1 and the
+    probability curve agree bit for bit with the eager paths (short last batches run eagerly in both)."""
+    from torch.utils.data import DataLoader, Dataset
+    import src.train as tr
+    import src.utils.prob_curve as pc
+    from src.loss import FocalLoss
+    from src.models.slowfast import SlowFast
+    from src.optim import ClipAdamW
+
+    class Clips(Dataset):
+        def __init__(self):
+            g = torch.Generator().manual_seed(7)
+            self.v = torch.randn(10, 3, 8, 32, 32, generator=g); self.y = torch.arange(10) % 2
+
+        def __len__(self):
+            return 10
+
+        def __getitem__(self, i):
+            return self.v[i], self.y[i]
+
+    torch.manual_seed(8)
+    m = SlowFast(input_shape=(3, 8, 32, 32), layers=[1, 1, 1, 1], alpha=4, tau_fast=1, num_classes=2).cuda()
+    loss_fn = FocalLoss(torch.tensor([1.0, 1.0]).cuda(), 2.0)
+    opt = ClipAdamW(m.parameters(), lr=1e-3, max_norm=1.0)
+    loader = DataLoader(Clips(), batch_size=4, shuffle=False)                   # 4, 4, 2
+    frames = torch.randint(0, 256, (40, 40, 40, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(9)).cuda()
+    res = {}
+    old_t, old_p = tr._GRAPH_STEPS, pc._GRAPH
+    try:
+        for flag in (False, True):
+            tr._GRAPH_STEPS = pc._GRAPH = flag
+            val = tr.valid_per_epoch(loader, m, opt, loss_fn, "cuda:0", "single")
+            curve = pc.video_window_probabilities(m, frames, 8, 3, crop_size=32, windows_per_launch=4)
+            res[flag] = (val, curve)
+        assert m.__dict__.get("_md_graphed_eval") not in (None, False) and m.__dict__.get("_md_graphed_curve") not in (None, False)
+    finally:
+        tr._GRAPH_STEPS, pc._GRAPH = old_t, old_p
+        m.__dict__.pop("_md_graphed_eval", None); m.__dict__.pop("_md_graphed_curve", None)
+    assert res[False][0] == res[True][0]
+    assert np.array_equal(res[False][1][0], res[True][1][0]) and np.array_equal(res[False][1][1], res[True][1][1])

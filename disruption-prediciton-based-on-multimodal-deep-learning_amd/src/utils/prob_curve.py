@@ -110,7 +110,8 @@ def series_window_probabilities(model: torch.nn.Module, values: torch.Tensor, se
     with torch.no_grad():
         for at in range(0, n, W):
             m = min(W, n - at)
-            _softmax_columns(model(windows[at + 1:at + 1 + m].contiguous()), p0, cls, at)
+            x = windows[at + 1:at + 1 + m].contiguous()
+            _softmax_columns(graphed_forward(model, [x], "_md_graphed_curve") if (_GRAPH and m == W) else model(x), p0, cls, at)
     return p0.cpu().numpy(), cls.cpu().numpy()
 
 
@@ -252,7 +253,8 @@ def multi_window_probabilities(model: torch.nn.Module, frames: torch.Tensor, val
         for at in range(0, n, W):
             m = min(W, n - at)
             clip = preprocess_clips(frames[fidx[at:at + m]], crop_size)                   # gather of uint8 frames, then one launch
-            out = model(clip, values[ridx[at:at + m]].contiguous())
+            xs = [clip, values[ridx[at:at + m]].contiguous()]
+            out = graphed_forward(model, xs, "_md_graphed_curve") if (_GRAPH and m == W) else model(*xs)
             _softmax_columns(out, p0, cls, at)
     return p0.cpu().numpy(), cls.cpu().numpy()
 

@@ -130,6 +130,7 @@ class GraphedForward:
         streams.prepare(example_inputs[0].device)
         self.model = model
         self.training = model.training
+        self.use_stream = getattr(model, "use_stream", None)      # (fusion models: which heads run is a module attribute)
         self.shapes = tuple((tuple(t.shape), t.dtype) for t in example_inputs)
         self.inputs = [t.detach().clone() for t in example_inputs]
         side = torch.cuda.Stream()
@@ -144,7 +145,8 @@ class GraphedForward:
                 self.outputs = model(*self.inputs)
 
     def matches(self, inputs: Sequence[torch.Tensor]) -> bool:
-        return self.model.training == self.training and tuple((tuple(t.shape), t.dtype) for t in inputs) == self.shapes
+        return (self.model.training == self.training and getattr(self.model, "use_stream", None) == self.use_stream and
+                tuple((tuple(t.shape), t.dtype) for t in inputs) == self.shapes)
 
     def __call__(self, inputs: Sequence[torch.Tensor]):
         for dst, src in zip(self.inputs, inputs):

@@ -160,3 +160,45 @@ size_t pers_bres_bytes(int Kc8, int N16);
 size_t pers_fixed_bytes(int Cps, int N16);
 int pers_launch(const PersGeom& pg, size_t lds, int grid, bool f16, const float* src, const float* ps, const float* psh, float slope,
                 const float* wp, float* dst, float* stat, int accumulate, const PersBwd& bw, hipStream_t s);
+
+// ---- host-side helpers shared by conv_patch.hip and conv_wgrad.hip
+#include <cstdlib>
+static int pitch_for(int C8) {          // smallest 16*(4m+2) >= 16*C8
+  int u = C8;
+  while ((u & 3) != 2) ++u;
+  static const int add = getenv("MD_PITCH_ADD") ? atoi(getenv("MD_PITCH_ADD")) : 0;   // experiments only
+  return (u + add) * 16;
+}
+
+// Choose the output box (bt,by,bx), <= 128 pixels, minimising (boxes) x (MFMA rows + weighted patch pixels).
+// Choose the output box (bt,by,bx), <= 128 pixels, minimising (boxes) x (MFMA rows + weighted patch pixels) subject
+// to the LDS budget: `maxP` patch pixels at most, and a 25% penalty once the patch exceeds `softP` pixels (the size
+// up to which two workgroups still fit on one CU).  dgrad_s > 1: patch of a strided data gradient (source shrinks).
+static bool choose_box(int T, int H, int W, int kt, int kh, int kw, int st, int sh, int sw, int dgrad, int maxP, int softP,
+                       int* bt, int* by, int* bx, int pm = PM) {
+  double best = 1e300;
+  bool found = false;
+  auto pdim = [&](int b, int k, int s) { return dgrad ? (b + k - 2) / s + 2 : (b - 1) * s + k; };
+  for (int t = 1; t <= T && t <= 32; ++t) {
+    for (int x = 1; x <= pm; x *= 2) {
+      const int xe = x >= W ? W : x;     // powers of two, and the full width
+      int ymax = pm / (t * xe);
+      if (ymax >= 1) {
+        if (ymax > H) ymax = H;
+        for (int y = ymax; y >= 1; y = (y > 4 ? y / 2 : y - 1)) {
+          const double boxes = (double)md_cdiv(T, t) * md_cdiv(H, y) * md_cdiv(W, xe);
+          const long long patch = (long long)pdim(t, kt, st) * pdim(y, kh, sh) * pdim(xe, kw, sw);
+          if (patch > maxP) continue;
+          double cost = boxes * (pm + 0.6 * (double)patch);
+          if (patch > softP) cost *= 1.25;
+          if (cost < best) { best = cost; *bt = t; *by = y; *bx = xe; found = true; }
+        }
+      }
+      if (x >= W) break;
+    }
+  }
+  return found;
+}
+
+static unsigned magic_of(int d) { return d <= 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)d) + 1u; }
+static int ilog2_exact(int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; }

@@ -512,7 +512,10 @@ static int unit_backward(MdPlan* P, float* ws, int ui, int gb, int dxb, int accu
     in.data = ws + (u.in_unit >= 0 ? P->units[u.in_unit].xs_off : P->z[u.in_z].xs_off);
     in.scale = in.shift = nullptr;
   }
-  if (side_stream(P)) {
+  // timing experiments only (wrong gradients): MD_DBG_SKIP_WGRAD=1 leaves the weight gradients out of the step
+  static const int skip_wgrad = getenv("MD_DBG_SKIP_WGRAD") && atoi(getenv("MD_DBG_SKIP_WGRAD")) == 1;
+  if (skip_wgrad) {
+  } else if (side_stream(P)) {
     // d_raw (G) is complete on the caller's stream here; the weight gradient reads it from the side stream
     hipEvent_t ready = P->ev_ready[P->ready_ix]; P->ready_ix ^= 1;
     if (hipEventRecord(ready, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(P->side, ready, 0) != hipSuccess)

@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from .train import train_per_epoch, valid_per_epoch
+from .utils.metrics import macro_f1
 
 
 class GradientBlending(nn.Module):
@@ -42,14 +43,50 @@ class GradientBlending(nn.Module):
         return loss_vis * self.vis_weight + loss_ts * self.ts_weight + loss_vis_ts * self.vis_ts_weight
 
 
+def evaluate_GB(test_loader, model, optimizer=None, device: Optional[str] = "cpu", threshold: float = 0.5):
+    """Macro-F1 of the fused, the vision and the 0D head of a ``*_GB`` model over a loader (reference
+    GradientBlending.py:116-163; used by its ``train_GB`` at :254-262 to monitor the three streams).
+
+    The reference takes ``softmax(out).max(1)[1]`` -- the arg-max index, 0 or 1 -- and compares THAT with ``threshold``, so
+    the prediction is the arg-max for any threshold in [0, 1) (softmax is monotone: arg-max of the logits).  Here the three
+    arg-maxes stay on the device in per-loader buffers and are read back once at the end instead of three ``.cpu()``
+    round trips per batch; ``optimizer`` is accepted for signature parity (the reference calls ``zero_grad`` under
+    ``no_grad``, which changes nothing that is measured)."""
+    if device is None:
+        device = torch.device("cuda:0")
+    model.to(device)
+    model.eval()
+    preds, labels = [], []
+    thr = float(threshold)
+    with torch.no_grad():
+        for data, target in test_loader:
+            out, out_vis, out_ts = model(data['video'].to(device), data['0D'].to(device))
+            idx = torch.stack([out.argmax(1), out_vis.argmax(1), out_ts.argmax(1)], 0)        # (3, B) int64 on the device
+            preds.append(idx.to(torch.float32) > thr)
+            labels.append(target.to(device).reshape(-1))
+    if not preds:
+        return 0.0, 0.0, 0.0
+    p = torch.cat(preds, 1).cpu().numpy().astype(np.float64)                                   # ONE read-back
+    y = torch.cat(labels, 0).cpu().numpy().astype(np.float64)
+    return macro_f1(y, p[0]), macro_f1(y, p[1]), macro_f1(y, p[2])
+
+
 def train_GB(train_loader, valid_loader, model, optimizer, scheduler, loss_fn: GradientBlending, device: str = "cpu",
              num_epoch: int = 64, verbose: Optional[int] = 8, save_best_dir: str = "./weights/best.pt",
              save_last_dir: str = "./weights/last.pt", exp_dir: Optional[str] = None, max_norm_grad: Optional[float] = None,
-             **_ignored):
+             criteria: str = "f1_score", test_for_check_per_epoch=None):
     """Fixed-weight gradient-blending training (reference GradientBlending.py:165-308): the epoch loop of
-    ``src.train`` with model_type "multi-GB" (the model returns fused, vision and 0D logits)."""
+    ``src.train`` with model_type "multi-GB" (the model returns fused, vision and 0D logits); the best checkpoint is chosen
+    by ``criteria`` ("f1_score", "acc" or "loss") exactly as at :276-296.  After every epoch the three per-stream macro-F1
+    scores of ``evaluate_GB`` over the training and the validation loader are taken as the reference does (:254-262; printed
+    with the epoch report) and kept in ``train_GB.stream_f1`` = {"train": [(fusion, video, 0D), ...], "valid": [...]} of
+    the last call -- the return value stays the reference's six lists.  TensorBoard logging and the per-epoch evaluation
+    figure (:201-205, :240-251) are presentation and are left out (``test_for_check_per_epoch`` is accepted and ignored)."""
     hist = {k: [] for k in ("train_loss", "train_acc", "train_f1", "valid_loss", "valid_acc", "valid_f1")}
-    best_f1 = 0.0
+    train_GB.stream_f1 = {"train": [], "valid": []}
+    best_acc, best_epoch, best_f1, best_loss = 0, 0, 0, float("inf")
+    if exp_dir and not os.path.isdir(exp_dir):
+        os.mkdir(exp_dir)
     for epoch in range(num_epoch):
         if hasattr(model, "update_use_stream"):
             model.update_use_stream("multi-GB")
@@ -57,13 +94,21 @@ def train_GB(train_loader, valid_loader, model, optimizer, scheduler, loss_fn: G
         vl, va, vf = valid_per_epoch(valid_loader, model, optimizer, loss_fn, device, "multi-GB")
         for k, v in zip(hist, (tl, ta, tf, vl, va, vf)):
             hist[k].append(v)
+        f1_tr = evaluate_GB(train_loader, model, optimizer, device, 0.5)
+        f1_va = evaluate_GB(valid_loader, model, optimizer, device, 0.5)
+        train_GB.stream_f1["train"].append(f1_tr); train_GB.stream_f1["valid"].append(f1_va)
         if verbose and epoch % verbose == 0:
-            print("epoch : {}, train loss : {:.3f}, valid loss : {:.3f}, train f1 : {:.3f}, valid f1 : {:.3f}".format(
-                epoch + 1, tl, vl, tf, vf))
-        torch.save(model.state_dict(), save_last_dir)
-        if vf > best_f1:
-            best_f1 = vf
+            print("# epoch: {}, train loss: {:.3f}, valid loss: {:.3f}".format(epoch + 1, tl, vl))
+            print("# train, fusion: {:.3f}, video: {:.3f}, 0D : {:.3f}".format(*f1_tr))
+            print("# valid, fusion: {:.3f}, video: {:.3f}, 0D : {:.3f}".format(*f1_va))
+        better = ((criteria == "acc" and best_acc < va) or (criteria == "f1_score" and best_f1 < vf)
+                  or (criteria == "loss" and best_loss > vl))
+        if better:
+            best_acc, best_f1, best_loss, best_epoch = va, vf, vl, epoch
             torch.save(model.state_dict(), save_best_dir)
+        torch.save(model.state_dict(), save_last_dir)
+    print("(Report) training process finished, best loss : {:.3f} and best acc : {:.3f}, best f1 : {:.3f}, best epoch : {}".format(
+        best_loss, best_acc, best_f1, best_epoch))
     return (hist["train_loss"], hist["train_acc"], hist["train_f1"], hist["valid_loss"], hist["valid_acc"], hist["valid_f1"])
 
 

@@ -39,6 +39,7 @@ SIGNATURES = {
     "md_set_exact_fp32": (C.c_int, [C.c_int]),
     "md_get_exact_fp32": (C.c_int, []),
     "md_set_pers_grid": (C.c_int, [C.c_int]),
+    "md_set_wgrad_form": (C.c_int, [C.c_int]),
     "md_conv_wpack_fwd_floats": (_SZ, [_DESC]),
     "md_conv_wpack_dgrad_floats": (_SZ, [_DESC]),
     "md_conv_pack_weights": (C.c_int, [_DESC, _P, _P, _P, _P]),

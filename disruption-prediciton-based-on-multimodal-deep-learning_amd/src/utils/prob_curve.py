@@ -329,3 +329,24 @@ def measure_computation_time(model: torch.nn.Module, input_shape: Tuple, n_sampl
             t_measures.append(time.perf_counter() - t0)
         del out
     return float(np.mean(t_measures)), float(np.std(t_measures)), t_measures
+
+
+def measure_computation_time_multi(model: torch.nn.Module, input_shape_vis: Tuple, input_shape_0D: Tuple, n_samples: int = 1,
+                                   device: str = "cuda:0"):
+    """Reference utility.py:1232-1265 (used by analysis/compute_time_multimodal.py:47-48): as measure_computation_time for a
+    two-input model -- one forward on a zero clip and a zero 0D window, host-to-device copies included, WITH a device
+    synchronisation before the clock is read.  A model that returns several logit sets (the *_GB variants) is timed as is."""
+    model.to(device)
+    model.eval()
+    t_measures = []
+    sample_vis = torch.zeros(input_shape_vis).pin_memory()
+    sample_0d = torch.zeros(input_shape_0D).pin_memory()
+    for _ in range(n_samples):
+        with torch.no_grad():
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = model(sample_vis.to(device, non_blocking=True), sample_0d.to(device, non_blocking=True))
+            torch.cuda.synchronize()
+            t_measures.append(time.perf_counter() - t0)
+        del out
+    return float(np.mean(t_measures)), float(np.std(t_measures)), t_measures

@@ -47,6 +47,9 @@ int md_get_exact_fp32(void);
  * boxes) to a grid of n workgroups, also on shapes too small to qualify by themselves; 0 restores the default
  * (one workgroup per CU, only where there are at least as many boxes).  Returns the previous value. */
 int md_set_pers_grid(int n);
+/* Test hook: 1 = weight gradients always on the first kernel form (the one that also reads the pre-split operand formats);
+ * 0 = automatic (default).  Returns the previous setting. */
+int md_set_wgrad_form(int first_form_only);
 
 /* ------------------------------------------------------------------------------------------------
  * Convolution as implicit GEMM on the matrix cores (replaces nn.Conv3d fwd/bwd as used by

@@ -334,6 +334,19 @@ def gb_loops_fixture():
         for name, h in zip(("train_loss", "train_acc", "train_f1", "valid_loss", "valid_acc", "valid_f1"), hist):
             rec["dyn/" + name] = np.array(h, dtype=np.float64)
         rec["dyn/weights"] = np.array([loss_gb.vis_weight, loss_gb.ts_weight, loss_gb.vis_ts_weight], dtype=np.float64)
+        # train_GB (:165-308, fixed weights, criteria "acc") and evaluate_GB (:116-163: macro-F1 of the three heads)
+        from src.GradientBlending import train_GB, evaluate_GB
+        model = FakeMultiModalGB(); model.update_use_stream("multi-GB")
+        opt = torch.optim.SGD(model.parameters(), lr=0.05)
+        loss_gb = GradientBlending(ce(), ce(), ce(), 0.2, 0.3, 0.5, 1.0)
+        hist = train_GB(tr, va, model, opt, None, loss_gb, "cpu", num_epoch=3, verbose=None, save_best_dir=best, save_last_dir=last,
+                        exp_dir=os.path.join(d, "exp2"), max_norm_grad=1.0, criteria="acc")
+        for name, h in zip(("train_loss", "train_acc", "train_f1", "valid_loss", "valid_acc", "valid_f1"), hist):
+            rec["fix/" + name] = np.array(h, dtype=np.float64)
+        rec["fix/evalgb_train"] = np.array(evaluate_GB(tr, model, opt, "cpu", 0.5), dtype=np.float64)
+        rec["fix/evalgb_valid"] = np.array(evaluate_GB(va, model, opt, "cpu", 0.5), dtype=np.float64)
+        best_sd = torch.load(best, weights_only=True)
+        rec["fix/best_head_bias"] = best_sd["head.bias"].double().numpy()
     np.savez_compressed(os.path.join(HERE, "gb_loops.npz"), **rec)
     print("gb loops", w, rec["dyn/weights"])
 

@@ -241,9 +241,13 @@ def test_presplit_gradient_format_is_bit_identical(case, persistent):
         dx32 = ops.conv_dgrad_fmt(d, d32, False, wd)
         dxsp = ops.conv_dgrad_fmt(d, dsp, True, wd)
         assert torch.equal(dx32, dxsp), name
-        dw32 = ops.conv_wgrad_fmt(d, ops.view(xg), d32, False)
-        dwsp = ops.conv_wgrad_fmt(d, ops.view(xg), dsp, True)
-        torch.cuda.synchronize()
+        form = lib.md_set_wgrad_form(1)        # both launches on the kernel form that reads either format
+        try:
+            dw32 = ops.conv_wgrad_fmt(d, ops.view(xg), d32, False)
+            dwsp = ops.conv_wgrad_fmt(d, ops.view(xg), dsp, True)
+            torch.cuda.synchronize()
+        finally:
+            lib.md_set_wgrad_form(form)
         assert torch.equal(dw32, dwsp), name
     finally:
         lib.md_set_pers_grid(prev)
@@ -267,10 +271,14 @@ def test_weight_gradient_from_the_presplit_activation_copy_is_bit_identical(cin,
     dy = torch.zeros(N_, d.To, d.Ho, d.Wo, ops.cpad(cout)); dy[..., :cout] = torch.randn(N_, d.To, d.Ho, d.Wo, cout, generator=g) * 1e-3
     x, sc, sh, dy = x.cuda(), sc.cuda(), sh.cuda(), dy.cuda()
     rows = N_ * T * H * W
-    for with_bn in (True, False):
-        v = ops.view(x, sc, sh, 0.01) if with_bn else ops.view(x)
-        ref = ops.conv_wgrad(d, v, dy)
-        xs = ops.bn_act_split(v, rows, cin, x.device)
-        got = ops.conv_wgrad_xsplit(d, xs, dy)
-        torch.cuda.synchronize()
-        assert torch.equal(ref, got), (with_bn, float((ref - got).abs().max()))
+    form = N.lib().md_set_wgrad_form(1)            # the pre-split formats are read by the first kernel form only
+    try:
+        for with_bn in (True, False):
+            v = ops.view(x, sc, sh, 0.01) if with_bn else ops.view(x)
+            ref = ops.conv_wgrad(d, v, dy)
+            xs = ops.bn_act_split(v, rows, cin, x.device)
+            got = ops.conv_wgrad_xsplit(d, xs, dy)
+            torch.cuda.synchronize()
+            assert torch.equal(ref, got), (with_bn, float((ref - got).abs().max()))
+    finally:
+        N.lib().md_set_wgrad_form(form)

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from oracle.fake_multimodal import FakeMultiModalGB, loaders
-from src.GradientBlending import GB_estimate, GradientBlending, train_GB_dynamic
+from src.GradientBlending import GB_estimate, GradientBlending, evaluate_GB, train_GB, train_GB_dynamic
 
 
 def _ce():
@@ -52,6 +52,29 @@ def test_train_gb_dynamic_matches_reference(golden_dir, tmp_path):
     got = np.array([loss_gb.vis_weight, loss_gb.ts_weight, loss_gb.vis_ts_weight], dtype=np.float64)
     assert np.allclose(got, g["dyn/weights"], rtol=1e-4, atol=1e-6), (got, g["dyn/weights"])
     assert os.path.isfile(tmp_path / "best.pt") and os.path.isfile(tmp_path / "last.pt")
+
+
+def test_train_gb_and_evaluate_gb_match_reference(golden_dir, tmp_path):
+    """train_GB (fixed weights, criteria "acc": GradientBlending.py:165-308) and evaluate_GB (:116-163, macro-F1 of the fused /
+    vision / 0D heads) against the reference's own run on the same tiny model: histories, the three per-stream scores over
+    both loaders, and WHICH epoch was kept as best.pt (the head bias of the saved checkpoint)."""
+    g = np.load(os.path.join(golden_dir, "gb_loops.npz"))
+    tr, va = loaders(11)
+    model = FakeMultiModalGB(); model.update_use_stream("multi-GB")
+    opt = torch.optim.SGD(model.parameters(), lr=0.05)
+    loss_gb = GradientBlending(_ce(), _ce(), _ce(), 0.2, 0.3, 0.5, 1.0)
+    best = str(tmp_path / "best.pt")
+    hist = train_GB(tr, va, model, opt, None, loss_gb, "cpu", num_epoch=3, verbose=None, save_best_dir=best,
+                    save_last_dir=str(tmp_path / "last.pt"), exp_dir=str(tmp_path / "exp2"), max_norm_grad=1.0, criteria="acc")
+    for name, h in zip(("train_loss", "train_acc", "train_f1", "valid_loss", "valid_acc", "valid_f1"), hist):
+        tol = 1e-5 if "loss" in name else 1e-12
+        assert np.allclose(np.array(h, dtype=np.float64), g["fix/" + name], rtol=tol, atol=tol), (name, h, g["fix/" + name])
+    assert np.allclose(evaluate_GB(tr, model, opt, "cpu", 0.5), g["fix/evalgb_train"], atol=1e-12)
+    assert np.allclose(evaluate_GB(va, model, opt, "cpu", 0.5), g["fix/evalgb_valid"], atol=1e-12)
+    # the per-epoch monitor of train_GB: its last entry is what evaluate_GB gives on the final model
+    assert np.allclose(train_GB.stream_f1["valid"][-1], g["fix/evalgb_valid"], atol=1e-12) and len(train_GB.stream_f1["train"]) == 3
+    sd = torch.load(best, weights_only=True)
+    assert np.allclose(sd["head.bias"].double().numpy(), g["fix/best_head_bias"], rtol=1e-5, atol=1e-7)
 
 
 # ---- the same loops on the GPU, with the native MultiModalModel_GB ------------------------------------------------------------

@@ -165,13 +165,18 @@ __global__ void k_bn_eval_params(int C, int Cp, const float* __restrict__ gamma,
 // ---------------------------------------------------------------- BatchNorm backward
 // g = dA * leaky'_main(pre_main); closing form: dS = dZ * leaky'_alpha(act(skip) + act(main)), g = dS * leaky'(pre).
 // GIN: dA already holds g (the fused reduction of the consumer's data gradient multiplied by leaky' on the way out).
-template <bool APPLY, bool GIN = false>
-__global__ __launch_bounds__(256) void k_bn_bwd(const float* __restrict__ dA, View main, View skip, int flags,
+// Fused finalize (APPLY only, fin.partial != nullptr): instead of reading the coefficients that md_bn_bwd_finalize would have
+// written, every workgroup sums the partial rows itself (<= 256 rows of the 1024-thread reduction pass or of a persistent data
+// gradient; fp64, fixed order: row lanes r, r + nr, ..., then lane by lane) -- one dependent launch less per unit on the backward
+// chain; workgroup 0 also writes dgamma / dbeta.
+struct BnFin { const float* partial; int blocks; double inv_count; float* dgamma; float* dbeta; int C; };
+template <bool APPLY, bool GIN = false, int NTH = 256>
+__global__ __launch_bounds__(NTH) void k_bn_bwd(const float* __restrict__ dA, View main, View skip, int flags,
                                                 float alpha, const float* __restrict__ mean,
                                                 const float* __restrict__ invstd, const float* __restrict__ coef,
                                                 int64_t rows, int C4, float* __restrict__ partial,
-                                                float* __restrict__ d_raw, float* __restrict__ dS) {
-  __shared__ float4 red[256];
+                                                float* __restrict__ d_raw, float* __restrict__ dS, BnFin fin) {
+  __shared__ float4 red[NTH];
   // The reduction pass walks the tensor back to front: dA was just written front to back by the data-gradient kernel,
   // and the apply pass that follows (front to back) then starts on what this pass touched last.
   const int has_skip = flags & 1;
@@ -179,12 +184,50 @@ __global__ __launch_bounds__(256) void k_bn_bwd(const float* __restrict__ dA, Vi
   RowWalk w = row_walk(rows, C4, bid);
   const int Cp = C4 * 4;
   float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1;
+  float4 fc1 = make_float4(0.f, 0.f, 0.f, 0.f), fc2 = fc1;
+  if (APPLY && fin.partial) {
+    __shared__ double fred[8][257];
+    const int nrp = 256 / C4;                      // row lanes of the prologue: the first nrp * C4 <= 256 threads
+    const bool pl = w.r < nrp;
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (pl) {
+      for (int i = w.r; i < fin.blocks; i += nrp) {
+        const float4 s1 = *(const float4*)(fin.partial + (size_t)i * 2 * Cp + w.c4 * 4);
+        const float4 s2 = *(const float4*)(fin.partial + (size_t)i * 2 * Cp + Cp + w.c4 * 4);
+        a[0] += s1.x; a[1] += s1.y; a[2] += s1.z; a[3] += s1.w;
+        a[4] += s2.x; a[5] += s2.y; a[6] += s2.z; a[7] += s2.w;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) fred[k][threadIdx.x] = a[k];
+    }
+    __syncthreads();
+    if (pl && w.r == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { double t = fred[k][w.c4]; for (int r = 1; r < nrp; ++r) t += fred[k][r * C4 + w.c4]; fred[k][w.c4] = t; }
+    }
+    __syncthreads();
+    if (w.active) {
+      double g[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) g[k] = fred[k][w.c4];
+      fc1 = make_float4((float)(g[0] * fin.inv_count), (float)(g[1] * fin.inv_count), (float)(g[2] * fin.inv_count), (float)(g[3] * fin.inv_count));
+      fc2 = make_float4((float)(g[4] * fin.inv_count), (float)(g[5] * fin.inv_count), (float)(g[6] * fin.inv_count), (float)(g[7] * fin.inv_count));
+      if (blockIdx.x == 0 && w.r == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = w.c4 * 4 + e;
+          if (c < fin.C) { if (fin.dbeta) fin.dbeta[c] = (float)g[e]; if (fin.dgamma) fin.dgamma[c] = (float)g[4 + e]; }
+        }
+      }
+    }
+  }
   if (w.active) {
     const ChanConst km = load_cc(main, w.c4);
     ChanConst ks; if (has_skip) ks = load_cc(skip, w.c4);
     const float4 mu = *(const float4*)(mean + w.c4 * 4), is = *(const float4*)(invstd + w.c4 * 4);
     float4 c1, c2;
-    if (APPLY) { c1 = *(const float4*)(coef + w.c4 * 4); c2 = *(const float4*)(coef + Cp + w.c4 * 4); }
+    if (APPLY && !fin.partial) { c1 = *(const float4*)(coef + w.c4 * 4); c2 = *(const float4*)(coef + Cp + w.c4 * 4); }
+    if (APPLY && fin.partial) { c1 = fc1; c2 = fc2; }
     // one row: same arithmetic and the same accumulation order whatever the unrolling below
     auto one = [&](size_t o, float4 raw, float4 d, float4 sraw) {
       const float4 pre = pre_of(main, km, raw);
@@ -426,17 +469,24 @@ extern "C" int md_residual_fwd(const MdActView* skip, const MdActView* main, flo
   return MD_OK;
 }
 
-extern "C" int32_t md_bn_bwd_blocks(int64_t rows, int32_t C) {
-  if (check_rows(rows, C) != MD_OK) return 0;
-  const int C4 = md_cpad(C) / 4;
-  const int nr = 256 / C4;
-  static const int cap = getenv("MD_BN_RED_CAP") ? atoi(getenv("MD_BN_RED_CAP")) : 2048;
-  static const int per = getenv("MD_BN_RED_ROWS") ? atoi(getenv("MD_BN_RED_ROWS")) : 16;
-  int64_t b = md_cdiv64(rows, (int64_t)nr * per);
+// Geometry of the BatchNorm-backward passes: at most 256 workgroups (= partial rows, so that the apply pass can sum them in its
+// prologue); 256 threads each while 16 rows per row lane are enough for that, 1024 threads for the large tensors.
+static int bn_pass_geom(int64_t rows, int C4, int per, int* nth) {
+  static const int cap = getenv("MD_BN_RED_CAP") ? atoi(getenv("MD_BN_RED_CAP")) : 256;
+  int64_t b = md_cdiv64(rows, (int64_t)(256 / C4) * per);
+  *nth = 256;
+  if (b > cap) { *nth = 1024; b = md_cdiv64(rows, (int64_t)(1024 / C4) * per); }
   if (b < 1) b = 1;
   if (b > cap) b = cap;
-  return (int32_t)b;
+  return (int)b;
 }
+extern "C" int32_t md_bn_bwd_blocks(int64_t rows, int32_t C) {
+  if (check_rows(rows, C) != MD_OK) return 0;
+  static const int per = getenv("MD_BN_RED_ROWS") ? atoi(getenv("MD_BN_RED_ROWS")) : 16;
+  int nth;
+  return bn_pass_geom(rows, md_cpad(C) / 4, per, &nth);
+}
+static const BnFin kNoFin = {nullptr, 0, 0.0, nullptr, nullptr, 0};
 
 extern "C" int md_bn_bwd_reduce(const float* dA, const MdActView* main, const MdActView* skip, float alpha,
                                 const float* mean, const float* invstd, int64_t rows, int32_t C, float* partial,
@@ -445,9 +495,15 @@ extern "C" int md_bn_bwd_reduce(const float* dA, const MdActView* main, const Md
   int rc = check_rows(rows, C); if (rc) return rc;
   const int C4 = md_cpad(C) / 4;
   static const int fwd_order = getenv("MD_BN_RED_FWD") ? 2 * (atoi(getenv("MD_BN_RED_FWD")) != 0) : 0;
-  MD_KLAUNCH(k_bn_bwd<false>, dim3(md_bn_bwd_blocks(rows, C)), dim3(256), 0, (hipStream_t)stream, dA,
-                     to_view(main), to_view(skip), (skip != nullptr ? 1 : 0) | fwd_order, alpha, mean, invstd, (const float*)nullptr,
-                     rows, C4, partial, (float*)nullptr, (float*)nullptr);
+  static const int per = getenv("MD_BN_RED_ROWS") ? atoi(getenv("MD_BN_RED_ROWS")) : 16;
+  int nth; const int nb = bn_pass_geom(rows, C4, per, &nth);
+  const int flags = (skip != nullptr ? 1 : 0) | fwd_order;
+  if (nth == 1024)
+    MD_KLAUNCH((k_bn_bwd<false, false, 1024>), dim3(nb), dim3(1024), 0, (hipStream_t)stream, dA, to_view(main), to_view(skip), flags, alpha,
+               mean, invstd, (const float*)nullptr, rows, C4, partial, (float*)nullptr, (float*)nullptr, kNoFin);
+  else
+    MD_KLAUNCH((k_bn_bwd<false, false, 256>), dim3(nb), dim3(256), 0, (hipStream_t)stream, dA, to_view(main), to_view(skip), flags, alpha,
+               mean, invstd, (const float*)nullptr, rows, C4, partial, (float*)nullptr, (float*)nullptr, kNoFin);
   MD_CHECK_LAUNCH();
   return MD_OK;
 }
@@ -472,7 +528,34 @@ extern "C" int md_bn_bwd_apply(const float* dA, const MdActView* main, const MdA
   const int C4 = md_cpad(C) / 4;
   MD_KLAUNCH(k_bn_bwd<true>, dim3(stream_blocks(rows, C4)), dim3(256), 0, (hipStream_t)stream, dA, to_view(main),
                      to_view(skip), skip != nullptr ? 1 : 0, alpha, mean, invstd, coef, rows, C4, (float*)nullptr,
-                     d_raw, dS);
+                     d_raw, dS, kNoFin);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+// Finalize + apply in one launch (fp32 d_raw): the apply pass sums the `blocks` (<= 256) partial rows of the reduction pass -- or of
+// a data gradient's fused reduction, g_in != 0 -- itself and writes dgamma / dbeta; no coefficient buffer, no finalize launch.
+extern "C" int md_bn_bwd_apply_fused(const float* dA, int g_in, const MdActView* main, const MdActView* skip, float alpha,
+                                     const float* mean, const float* invstd, const float* partial, int32_t blocks, int64_t count,
+                                     float* dgamma, float* dbeta, int64_t rows, int32_t C, float* d_raw, float* dS, void* stream) {
+  if (!dA || !main || !main->data || !mean || !invstd || !partial || !d_raw) return MD_ERR_NULL;
+  if (skip != nullptr && !dS) return MD_ERR_NULL;
+  if (g_in && (skip != nullptr || !main->scale)) return MD_ERR_UNSUPPORTED;
+  if (blocks <= 0 || blocks > 256 || count <= 0) return MD_ERR_BAD_SHAPE;
+  int rc = check_rows(rows, C); if (rc) return rc;
+  const int C4 = md_cpad(C) / 4;
+  // geometry of the plain apply pass (many 256-thread workgroups: the streaming part measured 14 % slower as 256 workgroups of
+  // 1024 threads, profiles/r03k); MD_BN_APPLY_1024=1 keeps that form for experiments
+  static const int big = getenv("MD_BN_APPLY_1024") && atoi(getenv("MD_BN_APPLY_1024")) == 1;
+  int nth = 256; int nb = stream_blocks(rows, C4);
+  if (big) nb = bn_pass_geom(rows, C4, 8, &nth);
+  const BnFin fin = {partial, blocks, 1.0 / (double)count, dgamma, dbeta, C};
+  const int flags = skip != nullptr ? 1 : 0;
+#define LAUNCH_APPLY_FUSED(GIN_, NTH_)                                                                                            \
+  MD_KLAUNCH((k_bn_bwd<true, GIN_, NTH_>), dim3(nb), dim3(NTH_), 0, (hipStream_t)stream, dA, to_view(main), to_view(skip), flags, alpha, \
+             mean, invstd, (const float*)nullptr, rows, C4, (float*)nullptr, d_raw, dS, fin)
+  if (g_in) { if (nth == 1024) LAUNCH_APPLY_FUSED(true, 1024); else LAUNCH_APPLY_FUSED(true, 256); }
+  else { if (nth == 1024) LAUNCH_APPLY_FUSED(false, 1024); else LAUNCH_APPLY_FUSED(false, 256); }
   MD_CHECK_LAUNCH();
   return MD_OK;
 }
@@ -491,10 +574,10 @@ extern "C" int md_bn_bwd_apply_fmt(const float* dA, int g_in, const MdActView* m
     if (g_in) {
       if (!main->scale) return MD_ERR_NULL;
       MD_KLAUNCH((k_bn_bwd<true, true>), dim3(stream_blocks(rows, C4)), dim3(256), 0, (hipStream_t)stream, dA, to_view(main),
-                 to_view(nullptr), 0, 1.f, mean, invstd, coef, rows, C4, (float*)nullptr, (float*)d_raw, (float*)nullptr);
+                 to_view(nullptr), 0, 1.f, mean, invstd, coef, rows, C4, (float*)nullptr, (float*)d_raw, (float*)nullptr, kNoFin);
     } else {
       MD_KLAUNCH(k_bn_bwd<true>, dim3(stream_blocks(rows, C4)), dim3(256), 0, (hipStream_t)stream, dA, to_view(main),
-                 to_view(skip), skip != nullptr ? 1 : 0, alpha, mean, invstd, coef, rows, C4, (float*)nullptr, (float*)d_raw, dS);
+                 to_view(skip), skip != nullptr ? 1 : 0, alpha, mean, invstd, coef, rows, C4, (float*)nullptr, (float*)d_raw, dS, kNoFin);
     }
     MD_CHECK_LAUNCH();
     return MD_OK;
@@ -573,7 +656,7 @@ extern "C" int md_bn_bwd_apply_g(const float* g, const MdActView* main, const fl
   int rc = check_rows(rows, C); if (rc) return rc;
   const int C4 = md_cpad(C) / 4;
   MD_KLAUNCH((k_bn_bwd<true, true>), dim3(stream_blocks(rows, C4)), dim3(256), 0, (hipStream_t)stream, g, to_view(main),
-             to_view(nullptr), 0, 1.f, mean, invstd, coef, rows, C4, (float*)nullptr, d_raw, (float*)nullptr);
+             to_view(nullptr), 0, 1.f, mean, invstd, coef, rows, C4, (float*)nullptr, d_raw, (float*)nullptr, kNoFin);
   MD_CHECK_LAUNCH();
   return MD_OK;
 }

@@ -84,5 +84,13 @@ const Wgrad2Plan* wgrad2_lookup(const MdConvDesc* d, int beside);     // nullptr
 size_t wgrad2_workspace_floats(const Wgrad2Plan* p);
 int wgrad2_launch(const Wgrad2Plan* p, const MdConvDesc* d, const float* src, const float* ps, const float* psh, float slope,
                   const float* dy, float* dw, float* slab, hipStream_t s);
+// Deferred reduction of second-form weight gradients (the executor batches the slab reductions of a backward range into one
+// launch): wgrad_partial runs only the slab-producing kernel and describes the pending reduction.
+struct WgradPending { const Wgrad2Plan* p; int Cout, Cin; const float* slab; float* dw; };
+int wgrad_partial(const MdConvDesc* d, const float* src, const float* ps, const float* psh, float slope, const float* dy, float* dw,
+                  float* slab, hipStream_t s, WgradPending* out);      // MD_ERR_UNSUPPORTED: not a second-form geometry
+int wgrad2_launch_partial(const Wgrad2Plan* p, const float* src, const float* ps, const float* psh, float slope, const float* dy,
+                          float* slab, hipStream_t s);
+int wgrad2_reduce_batch(int n, const WgradPending* items, hipStream_t s);
 int patch_pack_batch(int n, const MdConvDesc* const* descs, const int* dgrad, const float* const* w, float* const* outs,
                      unsigned char* handled, hipStream_t s);

@@ -705,7 +705,7 @@ const WgradPlan* wgrad_lookup(const MdConvDesc* d, int xpitch, int xc0, int dw_c
     // CUs to occupy.  The executor runs weight gradients on a side stream next to the BatchNorm-backward / data-gradient
     // chain (plan.hip); leaving part of the chip to that chain measured best at 160 of 256 (96: 992, 128: 1088,
     // 160: 1097, 192: 1085, 256: 1068 clips/s); with the side stream switched off the kernel takes the whole chip.
-    static const int side_off = getenv("MD_WGRAD_STREAM") && atoi(getenv("MD_WGRAD_STREAM")) == 0;
+    static const int side_off = !(getenv("MD_WGRAD_STREAM") && atoi(getenv("MD_WGRAD_STREAM")) == 1);     // round 3: one stream unless asked
     // Outside the executor (the composable models: a weight gradient runs alone on its stream) the kernel takes the whole chip as
     // well: ViViT cfg3 captured step 4.23 -> 4.14 ms at 256 (512: 4.21, 1024: 4.24).
     static const int fill_env = getenv("MD_WGRAD_FILL") ? atoi(getenv("MD_WGRAD_FILL")) : 0;
@@ -734,6 +734,16 @@ bool wgrad_plan_xsplit_ok(const WgradPlan* p) { return !p->g.pack2 && p->g.xpitc
 size_t wgrad_patch_workspace_floats(const WgradPlan* p) {
   const size_t a = (size_t)p->nslices * p->g.nkt * 16 * p->g.N16, b = p->v2 ? wgrad2_workspace_floats(p->v2) : 0;
   return a > b ? a : b;
+}
+
+int wgrad_partial(const MdConvDesc* d, const float* src, const float* ps, const float* psh, float slope, const float* dy, float* dw,
+                  float* slab, hipStream_t s, WgradPending* out) {
+  const WgradPlan* p = wgrad_lookup(d);
+  if (!p || !p->v2 || g_wgrad_first_form.load()) return MD_ERR_UNSUPPORTED;
+  const int rc = wgrad2_launch_partial(p->v2, src, ps, psh, slope, dy, slab, s);
+  if (rc != MD_OK) return rc;
+  out->p = p->v2; out->Cout = d->Cout; out->Cin = d->Cin; out->slab = slab; out->dw = dw;
+  return MD_OK;
 }
 
 int wgrad_patch_launch(const WgradPlan* p, const MdConvDesc* d, const float* src, const float* ps, const float* psh,

@@ -244,6 +244,9 @@ __global__ __launch_bounds__(256, 2) void k_wgrad2(
 
   const int box_beg = blockIdx.x * g.boxes_per_wg;
   const int box_end = min(g.nboxes, box_beg + g.boxes_per_wg);
+  // experiment (MD_W2_STAGGER = dbg >> 8, units of 512 cycles): delay the second half of the grid -- the workgroups that join an
+  // already occupied CU -- so that the two workgroups of a CU do not run their matrix phases in step
+  if ((dbg >> 8) && blockIdx.x >= gridDim.x / 2) for (int i = 0; i < (dbg >> 8); ++i) __builtin_amdgcn_s_sleep(8);
   if (box_beg < box_end) issue();
   for (int box = box_beg; box < box_end; ++box) {
     __syncthreads();          // previous box fully consumed (first iteration: tables / scale in LDS)
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad2(
     __syncthreads();
     if (box + 1 < box_end) issue();      // in flight during the matrix phase
 #pragma unroll
-    for (int s = 0; s < ((dbg & 2) ? 0 : NS); ++s) {
+    for (int s = 0; s < (((dbg & 0xff) & 2) ? 0 : NS); ++s) {
       // The MFMA's 32 reduction slots of this step are pixels; lane group lg takes pixels {4lg..4lg+3} and
       // {16+4lg..16+4lg+3} of the step (any assignment works as long as A and B agree): a half-wave's first read
       // then covers 8 consecutive pixels, conflict free with the odd-multiple-of-32-byte pixel pitch.
@@ -306,8 +309,8 @@ __global__ __launch_bounds__(256, 2) void k_wgrad2(
 
 // dw[cout][cin][tap] = sum_slices slab[slice][((kg * taps + tap) * KTg + c16) * 16 + cin % 16][cout]   (fixed order)
 // Block = 64 outputs x 4 slice groups: slice group q sums slices q, q+4, ... with four independent chains.
-__global__ __launch_bounds__(256) void k_wgrad2_reduce(const float* __restrict__ slab, int nslices, int rows, int KTg, int taps, int N16,
-                                                       int Cout, int Cin, float* __restrict__ dw) {
+__device__ __forceinline__ void wgrad2_reduce_body(const float* __restrict__ slab, int nslices, int rows, int KTg, int taps, int N16,
+                                                   int Cout, int Cin, float* __restrict__ dw) {
   __shared__ float red[4][64];
   const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int idx = blockIdx.x * 64 + o;                         // over [rows][N16], cout fastest
@@ -334,6 +337,11 @@ __global__ __launch_bounds__(256) void k_wgrad2_reduce(const float* __restrict__
     const int tap = lt / KTg; const int c = ((kg * KTg) + (lt - tap * KTg)) * 16 + (krow & 15);
     if (co < Cout && c < Cin) dw[((size_t)co * Cin + c) * taps + tap] = s;
   }
+}
+
+__global__ __launch_bounds__(256) void k_wgrad2_reduce(const float* __restrict__ slab, int nslices, int rows, int KTg, int taps, int N16,
+                                                       int Cout, int Cin, float* __restrict__ dw) {
+  wgrad2_reduce_body(slab, nslices, rows, KTg, taps, N16, Cout, Cin, dw);
 }
 
 struct Wgrad2Plan { W2Geom g; size_t lds; int nslices; };
@@ -416,12 +424,11 @@ const Wgrad2Plan* wgrad2_lookup(const MdConvDesc* d, int beside) {
   Wgrad2Plan* wp = nullptr;
   W2Geom g; size_t lds = 0;
   if (wgrad2_build(d, &g, &lds)) {
-    // one slab of partial sums per workgroup: two resident workgroups per CU on `fill` CUs.  Beside the executor's
-    // backward chain (side stream) part of the chip is left to that chain, as for the first form.
+    // one slab of partial sums per workgroup: two resident workgroups per CU, the whole chip whatever the executor's schedule
+    // (the plan, and with it the summation order, does not depend on the schedule: both give the same bits)
     static const int fill_env = getenv("MD_WGRAD_FILL") ? atoi(getenv("MD_WGRAD_FILL")) : 0;
-    static const int side_off = getenv("MD_WGRAD_STREAM") && atoi(getenv("MD_WGRAD_STREAM")) == 0;
-    static const int fill_beside = getenv("MD_WGRAD2_BESIDE") ? atoi(getenv("MD_WGRAD2_BESIDE")) : 160;
-    const int fill = fill_env ? fill_env : ((side_off || !beside) ? 256 : fill_beside);
+    const int fill = fill_env ? fill_env : 256;
+    (void)beside;
     int want = md_cdiv(fill * 2, g.nkg * g.nng);
     if (want > g.nboxes) want = g.nboxes;
     if (want < 1) want = 1;
@@ -445,7 +452,7 @@ static int wgrad2_launch_one(const Wgrad2Plan* p, const float* src, const float*
     set_ = true;
   }
   dim3 grid(p->nslices, g.nkg * g.nng);
-  static const int dbg = getenv("MD_DBG2") ? atoi(getenv("MD_DBG2")) : 0;
+  static const int dbg = (getenv("MD_DBG2") ? atoi(getenv("MD_DBG2")) : 0) | ((getenv("MD_W2_STAGGER") ? atoi(getenv("MD_W2_STAGGER")) : 0) << 8);
   static const size_t pad = getenv("MD_W2_PAD_KB") ? (size_t)atoi(getenv("MD_W2_PAD_KB")) * 1024 : 0;      // experiments: force fewer workgroups per CU
   MD_KLAUNCH((k_wgrad2<KTW, NREP, 2>), grid, dim3(256), p->lds + pad, s, g, src, ps, psh, slope, dy, slab, dbg);
   MD_CHECK_LAUNCH();
@@ -463,20 +470,50 @@ static int wgrad2_launch_nr(const Wgrad2Plan* p, const float* src, const float* 
   }
 }
 
+int wgrad2_launch_partial(const Wgrad2Plan* p, const float* src, const float* ps, const float* psh, float slope, const float* dy,
+                          float* slab, hipStream_t s) {
+  switch (p->g.ktw) {
+    case 2: return wgrad2_launch_nr<2>(p, src, ps, psh, slope, dy, slab, s);
+    case 3: return wgrad2_launch_nr<3>(p, src, ps, psh, slope, dy, slab, s);
+    case 4: return wgrad2_launch_nr<4>(p, src, ps, psh, slope, dy, slab, s);
+    default: return wgrad2_launch_nr<5>(p, src, ps, psh, slope, dy, slab, s);
+  }
+}
+
 int wgrad2_launch(const Wgrad2Plan* p, const MdConvDesc* d, const float* src, const float* ps, const float* psh, float slope,
                   const float* dy, float* dw, float* slab, hipStream_t s) {
   const W2Geom& g = p->g;
-  int rc;
-  switch (g.ktw) {
-    case 2: rc = wgrad2_launch_nr<2>(p, src, ps, psh, slope, dy, slab, s); break;
-    case 3: rc = wgrad2_launch_nr<3>(p, src, ps, psh, slope, dy, slab, s); break;
-    case 4: rc = wgrad2_launch_nr<4>(p, src, ps, psh, slope, dy, slab, s); break;
-    default: rc = wgrad2_launch_nr<5>(p, src, ps, psh, slope, dy, slab, s); break;
-  }
+  const int rc = wgrad2_launch_partial(p, src, ps, psh, slope, dy, slab, s);
   if (rc != MD_OK) return rc;
   const int rows = g.nkg * g.nktg * 16;
   MD_KLAUNCH(k_wgrad2_reduce, dim3(md_cdiv(rows * g.N16, 64)), dim3(256), 0, s, slab, p->nslices, rows, g.KTg, g.taps, g.N16, d->Cout,
              d->Cin, dw);
   MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+// ---- the slab reductions of several weight gradients in one launch (blockIdx.y = which one); same sums, same order
+#define W2_RB_MAX 40
+struct W2RedItem { const float* slab; float* dw; int nslices, rows, KTg, taps, N16, Cout, Cin, pad; };
+struct W2RedBatch { W2RedItem it[W2_RB_MAX]; };
+__global__ __launch_bounds__(256) void k_wgrad2_reduce_batch(W2RedBatch b) {
+  const W2RedItem& q = b.it[blockIdx.y];
+  if ((int)blockIdx.x * 64 >= q.rows * q.N16) return;
+  wgrad2_reduce_body(q.slab, q.nslices, q.rows, q.KTg, q.taps, q.N16, q.Cout, q.Cin, q.dw);
+}
+int wgrad2_reduce_batch(int n, const WgradPending* items, hipStream_t s) {
+  for (int base = 0; base < n; base += W2_RB_MAX) {
+    W2RedBatch b; int cnt = 0, maxb = 0;
+    for (int i = base; i < n && cnt < W2_RB_MAX; ++i, ++cnt) {
+      const W2Geom& g = items[i].p->g;
+      W2RedItem& q = b.it[cnt];
+      q.slab = items[i].slab; q.dw = items[i].dw; q.nslices = items[i].p->nslices; q.rows = g.nkg * g.nktg * 16; q.KTg = g.KTg;
+      q.taps = g.taps; q.N16 = g.N16; q.Cout = items[i].Cout; q.Cin = items[i].Cin; q.pad = 0;
+      const int nb = md_cdiv(q.rows * q.N16, 64);
+      if (nb > maxb) maxb = nb;
+    }
+    MD_KLAUNCH(k_wgrad2_reduce_batch, dim3(maxb, cnt), dim3(256), 0, s, b);
+    MD_CHECK_LAUNCH();
+  }
   return MD_OK;
 }

@@ -12,6 +12,9 @@
 #include <new>
 #include "common.h"
 
+extern "C" int md_bn_bwd_apply_fused(const float* dA, int g_in, const MdActView* main, const MdActView* skip, float alpha,
+                                     const float* mean, const float* invstd, const float* partial, int32_t blocks, int64_t count,
+                                     float* dgamma, float* dbeta, int64_t rows, int32_t C, float* d_raw, float* dS, void* stream);
 extern "C" int md_bn_eval_params(int32_t C, const float* gamma, const float* beta, const float* rmean, const float* rvar,
                                  float eps, float* mean, float* invstd, float* scale, float* shift, void* stream);
 
@@ -25,6 +28,7 @@ struct Unit {
   size_t raw_off, stat_off, wf_off, wd_off;   // float offsets into the workspace
   int Cp;
   int split;        // d_raw of this unit is kept in the pre-split bf16 format (md_bn_bwd_apply_fmt)
+  size_t slab_off;  // this unit's weight-gradient slabs (kept until the batched reduction at the end of a backward range)
   size_t xs_off;    // pre-split bf16 copy of this unit's ACTIVATION (input of the weight gradients of its consumers); 0 = none
   int xsplit;       // this unit's weight gradient reads the pre-split copy of its input
 };
@@ -66,16 +70,24 @@ struct MdPlan {
   bool side_used = false;     // work was queued on the side stream since the last join
   int side_state = 0;         // 0 not tried, 1 available, -1 unavailable (then everything stays on the caller's stream)
   bool defer_join = false;    // md_plan_backward_range leaves the join to the caller (md_plan_join)
+  bool side_wanted = false;   // md_plan_use_side_stream(1) was called
   // red_blocks[u] > 0: the data gradient of u's consumer has already left g = dA * leaky'(bn(y_u)) in the gradient buffer
   // and that many partial rows of the BatchNorm-backward reduction in the partial buffer (md_conv_dgrad_bnred)
   std::vector<int> red_blocks;
+  // second-form weight gradients whose slab reduction is still to be launched (md_plan_backward_range flushes them in ONE launch:
+  // measured 32 reductions of 6-10 us, each behind a dependent-launch gap, on the critical chain of the one-stream schedule)
+  std::vector<WgradPending> pending;
+  bool batch_reduce = true;
 };
 
+// Round 3: the default schedule is ONE stream.  With two workgroups per CU the weight-gradient kernels fill the chip on their own,
+// and beside the data-gradient chain the two queues only take turns (profiles/r03_schedule_sweep.txt: 6.07 ms serial, 6.09-6.22 with
+// all or part of the weight gradients overlapped); the side stream remains for md_plan_use_side_stream(1) / MD_WGRAD_STREAM=1.
 static bool side_stream(MdPlan* P) {
   if (P->side_state) return P->side_state > 0;
-  static const int off = getenv("MD_WGRAD_STREAM") && atoi(getenv("MD_WGRAD_STREAM")) == 0;
+  static const int on = getenv("MD_WGRAD_STREAM") && atoi(getenv("MD_WGRAD_STREAM")) == 1;
+  if (!on && !P->side_wanted) return false;          // (state stays "not tried": an explicit request may still come)
   P->side_state = -1;
-  if (off) return false;
   int lo = 0, hi = 0;
   if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); return false; }
   // measured: the side stream at the HIGHEST priority gives 6.36 ms/step, at the lowest 6.42 (the weight gradients are the
@@ -204,7 +216,12 @@ extern "C" int md_plan_create(int32_t B, int32_t T, int32_t H, int32_t W, const 
     P->part2_off = take(p2 ? p2 : 4);
   }
   size_t smax = 0;
-  for (auto& u : P->units) { const size_t n = md_conv_wgrad_workspace_floats(&u.d); if (n > smax) smax = n; }
+  static const int batch_off = getenv("MD_WGRAD_BATCH_REDUCE") && atoi(getenv("MD_WGRAD_BATCH_REDUCE")) == 0;
+  P->batch_reduce = !batch_off;
+  for (auto& u : P->units) {
+    const size_t n = md_conv_wgrad_workspace_floats(&u.d); if (n > smax) smax = n;
+    u.slab_off = P->batch_reduce ? take(n) : 0;          // own slabs: they outlive the unit's kernel (0.73 GB in all at the BASELINE shape)
+  }
   P->slab_off = take(smax);
   P->coef_off = take(2 * 1024);
   P->gmax = gmax;
@@ -304,9 +321,11 @@ struct ProfScope {
 extern "C" int md_plan_use_side_stream(MdPlan* P, int enable) {
   if (!P) return MD_ERR_NULL;
   if (!enable) {
+    P->side_wanted = false;
     if (P->side_state > 0) { if (hipStreamSynchronize(P->side) != hipSuccess) return MD_ERR_LAUNCH; P->side_state = -2; }
     else if (P->side_state == 0) P->side_state = -3;           // never create it
   } else {
+    P->side_wanted = true;
     if (P->side_state == -2) P->side_state = 1;                 // re-enable the existing stream
     else if (P->side_state == -3) P->side_state = 0;            // create on next use
   }
@@ -486,6 +505,33 @@ extern "C" int md_plan_forward(MdPlan* P, const float* x, const float* const* w,
   return MD_OK;
 }
 
+// md_bn_bwd_apply_fused (the apply pass sums the partial rows itself, no finalize launch) is available but OFF in the executor:
+// measured slower (profiles/r03_bn_fused_finalize.txt: 6.31 ms per step with the prologue in each of the apply pass's 4096 workgroups,
+// 6.15 ms with 256 workgroups of 1024 threads, 5.99 ms with the separate 5 us finalize launch).  MD_BN_FUSED_FIN=1 switches it on.
+static bool bn_fused_fin() {
+  static const int on = getenv("MD_BN_FUSED_FIN") && atoi(getenv("MD_BN_FUSED_FIN")) == 1;
+  return on;
+}
+
+// Weight gradient of unit ui on stream s: second-form geometries only produce their slabs here (own slab region) and queue the
+// reduction for flush_pending; everything else (the stem's pixel-pair form, pre-split operands) reduces at once.
+static int unit_wgrad(MdPlan* P, float* ws, int ui, const MdActView& in, float* G, float* dw, void* s) {
+  const Unit& u = P->units[ui];
+  if (P->batch_reduce && !u.xsplit && !u.split) {
+    WgradPending pd;
+    const int rc = wgrad_partial(&u.d, in.data, in.scale, in.shift, in.slope, G, dw, ws + u.slab_off, (hipStream_t)s, &pd);
+    if (rc == MD_OK) { P->pending.push_back(pd); return MD_OK; }
+    if (rc != MD_ERR_UNSUPPORTED) return rc;
+  }
+  return md_conv_wgrad_fmt2(&u.d, &in, u.xsplit, G, u.split, dw, ws + P->slab_off, s);
+}
+static int flush_pending(MdPlan* P, void* s) {
+  if (P->pending.empty()) return MD_OK;
+  const int rc = wgrad2_reduce_batch((int)P->pending.size(), P->pending.data(), (hipStream_t)s);
+  P->pending.clear();
+  return rc;
+}
+
 // BN-backward of unit ui given dA in G[gb] (overwritten with d_raw), then wgrad and (optionally) dgrad.
 static int unit_backward(MdPlan* P, float* ws, int ui, int gb, int dxb, int accumulate, bool bn_done,
                          const float* const* w, float* const* dw, float* const* dgamma, float* const* dbeta, void* stream) {
@@ -495,16 +541,29 @@ static int unit_backward(MdPlan* P, float* ws, int ui, int gb, int dxb, int accu
   (void)w;
   if (!bn_done) {
     MdActView mainv = unit_out_view(P, ws, ui);
-    if (P->red_blocks[ui] > 0) {
+    // (fused_fin: the apply pass sums the <= 256 partial rows itself -- no finalize launch between the two passes)
+    const int rb = P->red_blocks[ui];
+    const bool fused_fin = bn_fused_fin() && !u.split && rb <= 256;
+    if (rb > 0) {
       // the consumer's data gradient already reduced: G holds g, the partial buffer its sums
-      RC(md_bn_bwd_finalize(ws + P->part_off, P->red_blocks[ui], u.d.Cout, u.rows, dgamma[ui], dbeta[ui], ws + P->coef_off, stream));
-      RC(md_bn_bwd_apply_fmt(G, 1, &mainv, nullptr, 1.f, st, st + u.Cp, ws + P->coef_off, u.rows, u.d.Cout, G, u.split, nullptr, stream));
+      if (fused_fin) {
+        RC(md_bn_bwd_apply_fused(G, 1, &mainv, nullptr, 1.f, st, st + u.Cp, ws + P->part_off, rb, u.rows, dgamma[ui], dbeta[ui], u.rows,
+                                 u.d.Cout, G, nullptr, stream));
+      } else {
+        RC(md_bn_bwd_finalize(ws + P->part_off, rb, u.d.Cout, u.rows, dgamma[ui], dbeta[ui], ws + P->coef_off, stream));
+        RC(md_bn_bwd_apply_fmt(G, 1, &mainv, nullptr, 1.f, st, st + u.Cp, ws + P->coef_off, u.rows, u.d.Cout, G, u.split, nullptr, stream));
+      }
       P->red_blocks[ui] = 0;
     } else {
       const int nb = md_bn_bwd_blocks(u.rows, u.d.Cout);
       RC(md_bn_bwd_reduce(G, &mainv, nullptr, 1.f, st, st + u.Cp, u.rows, u.d.Cout, ws + P->part_off, stream));
-      RC(md_bn_bwd_finalize(ws + P->part_off, nb, u.d.Cout, u.rows, dgamma[ui], dbeta[ui], ws + P->coef_off, stream));
-      RC(md_bn_bwd_apply_fmt(G, 0, &mainv, nullptr, 1.f, st, st + u.Cp, ws + P->coef_off, u.rows, u.d.Cout, G, u.split, nullptr, stream));
+      if (fused_fin) {
+        RC(md_bn_bwd_apply_fused(G, 0, &mainv, nullptr, 1.f, st, st + u.Cp, ws + P->part_off, nb, u.rows, dgamma[ui], dbeta[ui], u.rows,
+                                 u.d.Cout, G, nullptr, stream));
+      } else {
+        RC(md_bn_bwd_finalize(ws + P->part_off, nb, u.d.Cout, u.rows, dgamma[ui], dbeta[ui], ws + P->coef_off, stream));
+        RC(md_bn_bwd_apply_fmt(G, 0, &mainv, nullptr, 1.f, st, st + u.Cp, ws + P->coef_off, u.rows, u.d.Cout, G, u.split, nullptr, stream));
+      }
     }
   }
   MdActView in = unit_in_view(P, ws, ui);
@@ -521,12 +580,12 @@ static int unit_backward(MdPlan* P, float* ws, int ui, int gb, int dxb, int accu
     if (hipEventRecord(ready, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(P->side, ready, 0) != hipSuccess)
       return MD_ERR_LAUNCH;
     { ProfScope ps(P, KC_WGRAD, unit_flops(u), P->side);
-      RC(md_conv_wgrad_fmt2(&u.d, &in, u.xsplit, G, u.split, dw[ui], ws + P->slab_off, P->side)); }
+      RC(unit_wgrad(P, ws, ui, in, G, dw[ui], P->side)); }
     if (hipEventRecord(P->ev_done[gb], P->side) != hipSuccess) return MD_ERR_LAUNCH;
     P->done_pending[gb] = true; P->side_used = true;
   } else {
     ProfScope ps(P, KC_WGRAD, unit_flops(u), stream);
-    RC(md_conv_wgrad_fmt2(&u.d, &in, u.xsplit, G, u.split, dw[ui], ws + P->slab_off, stream));
+    RC(unit_wgrad(P, ws, ui, in, G, dw[ui], stream));
   }
   if (dxb >= 0) {
     RC(await_buffer(P, dxb, stream));
@@ -563,11 +622,17 @@ static int block_backward(MdPlan* P, float* ws, const Block& b, const float* con
   const int nb = md_bn_bwd_blocks(t2.rows, t2.d.Cout);
   float* Gp = ws + P->g_off[p];
   RC(md_bn_bwd_reduce(Gp, &mainv, &skipv, P->alpha, st, st + t2.Cp, t2.rows, t2.d.Cout, ws + P->part_off, stream));
-  RC(md_bn_bwd_finalize(ws + P->part_off, nb, t2.d.Cout, t2.rows, dgamma[b.c2t], dbeta[b.c2t], ws + P->coef_off, stream));
+  const bool fused_fin = bn_fused_fin() && !t2.split;
+  if (!fused_fin) RC(md_bn_bwd_finalize(ws + P->part_off, nb, t2.d.Cout, t2.rows, dgamma[b.c2t], dbeta[b.c2t], ws + P->coef_off, stream));
   RC(await_buffer(P, a, stream));
   RC(await_buffer(P, p, stream));
-  RC(md_bn_bwd_apply_fmt(Gp, 0, &mainv, &skipv, P->alpha, st, st + t2.Cp, ws + P->coef_off, t2.rows, t2.d.Cout,
-                         ws + P->g_off[a], t2.split, Gp, stream));
+  if (fused_fin) {
+    RC(md_bn_bwd_apply_fused(Gp, 0, &mainv, &skipv, P->alpha, st, st + t2.Cp, ws + P->part_off, nb, t2.rows, dgamma[b.c2t], dbeta[b.c2t],
+                             t2.rows, t2.d.Cout, ws + P->g_off[a], Gp, stream));
+  } else {
+    RC(md_bn_bwd_apply_fmt(Gp, 0, &mainv, &skipv, P->alpha, st, st + t2.Cp, ws + P->coef_off, t2.rows, t2.d.Cout,
+                           ws + P->g_off[a], t2.split, Gp, stream));
+  }
   RC(unit_backward(P, ws, b.c2t, a, bb, 0, true, w, dw, dgamma, dbeta, stream));
   RC(unit_backward(P, ws, b.c2s, bb, a, 0, false, w, dw, dgamma, dbeta, stream));
   RC(unit_backward(P, ws, b.c1t, a, bb, 0, false, w, dw, dgamma, dbeta, stream));
@@ -609,6 +674,7 @@ extern "C" int md_plan_backward_range(MdPlan* P, const float* dfeat, const float
     RC(unit_backward(P, ws, 1, p, q, 0, false, w, dw, dgamma, dbeta, stream));
     RC(unit_backward(P, ws, 0, q, -1, 0, false, w, dw, dgamma, dbeta, stream));
   }
+  RC(flush_pending(P, side_stream(P) ? (void*)P->side : stream));      // one launch reduces the slabs of every unit of this range
   if (P->defer_join) return MD_OK;    // the caller orders its consumers itself (md_plan_side_stream / md_plan_join)
   return join_side(P, stream);        // the weight gradients of this range are ordered before whatever follows
 }

@@ -62,6 +62,7 @@ SIGNATURES = {
     "md_bn_bwd_apply_g": (C.c_int, [_P, _VIEW, _P, _P, _P, _I64, _I32, _P, _P]),
     "md_conv_split_dy_ok": (C.c_int, [_DESC, C.c_int]),
     "md_bn_bwd_apply_fmt": (C.c_int, [_P, C.c_int, _VIEW, _VIEW, _F, _P, _P, _P, _I64, _I32, _P, C.c_int, _P, _P]),
+    "md_bn_bwd_apply_fused": (C.c_int, [_P, C.c_int, _VIEW, _VIEW, _F, _P, _P, _P, _I32, _I64, _P, _P, _I64, _I32, _P, _P, _P]),
     "md_conv_dgrad_fmt": (C.c_int, [_DESC, _P, C.c_int, _P, _P, C.c_int, _VIEW, _P, _P, _P, _P]),
     "md_conv_wgrad_fmt": (C.c_int, [_DESC, _VIEW, _P, C.c_int, _P, _P, _P]),
     "md_conv_wgrad_fmt2": (C.c_int, [_DESC, _VIEW, C.c_int, _P, C.c_int, _P, _P, _P]),

@@ -8,6 +8,7 @@ Tensors in the library's internal layout are channels-last ``[N, T, H, W, Cp]`` 
 from __future__ import annotations
 
 import ctypes as C
+import os
 import weakref
 from typing import Optional, Sequence, Tuple
 
@@ -323,7 +324,7 @@ def residual_fwd(skip: N.MdActView, main: N.MdActView, alpha: float, like: torch
 
 
 def bn_backward(dA: torch.Tensor, main: N.MdActView, st: torch.Tensor, Cc: int, skip: Optional[N.MdActView] = None,
-                alpha: float = 1.0):
+                alpha: float = 1.0, fused_finalize: bool = False):
     """Returns (d_raw, dS or None, dgamma, dbeta)."""
     require_cuda(dA, st)
     L = N.lib()
@@ -336,10 +337,16 @@ def bn_backward(dA: torch.Tensor, main: N.MdActView, st: torch.Tensor, Cc: int, 
             "md_bn_bwd_reduce")
     dgamma = torch.empty(Cc, device=dA.device, dtype=torch.float32)
     dbeta = torch.empty(Cc, device=dA.device, dtype=torch.float32)
-    coef = torch.empty((2, Cp), device=dA.device, dtype=torch.float32)
-    N.check(L.md_bn_bwd_finalize(_p(part), nb, Cc, rows, _p(dgamma), _p(dbeta), _p(coef), _stream()), "md_bn_bwd_finalize")
     d_raw = torch.empty_like(dA)
     dS = torch.empty_like(dA) if skip is not None else None
+    if fused_finalize:
+        # the apply pass sums the partial rows itself: one launch instead of finalize + apply (measured slower in the R(2+1)D
+        # step -- every workgroup of the apply pass repeats the sum -- so it is not the default)
+        N.check(L.md_bn_bwd_apply_fused(_p(dA), 0, C.byref(main), sk, float(alpha), _p(st[0]), _p(st[1]), _p(part), nb, rows,
+                                        _p(dgamma), _p(dbeta), rows, Cc, _p(d_raw), _p(dS), _stream()), "md_bn_bwd_apply_fused")
+        return d_raw, dS, dgamma, dbeta
+    coef = torch.empty((2, Cp), device=dA.device, dtype=torch.float32)
+    N.check(L.md_bn_bwd_finalize(_p(part), nb, Cc, rows, _p(dgamma), _p(dbeta), _p(coef), _stream()), "md_bn_bwd_finalize")
     N.check(L.md_bn_bwd_apply(_p(dA), C.byref(main), sk, float(alpha), _p(st[0]), _p(st[1]), _p(coef), rows, Cc, _p(d_raw),
                               _p(dS), _stream()), "md_bn_bwd_apply")
     return d_raw, dS, dgamma, dbeta

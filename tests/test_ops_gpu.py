@@ -167,6 +167,36 @@ def test_bn_forward_backward_unit(C, rows_shape):
     assert relerr(dgam.cpu(), gr.grad) < 2e-5 and relerr(dbet.cpu(), br.grad) < 2e-5
 
 
+@pytest.mark.parametrize("C,rows_shape", [(72, (2, 8, 64, 64)), (32, (4, 8, 64, 64)), (144, (1, 2, 12, 12))])
+def test_bn_backward_fused_finalize_large_and_small(C, rows_shape):
+    """BatchNorm-backward with the finalize folded into the apply pass (md_bn_bwd_apply_fused; the large shapes take the
+    1024-thread passes with at most 256 partial rows) against the three-launch form and against autograd in fp64."""
+    g = torch.Generator().manual_seed(C + 1)
+    Nn, T, H, W = rows_shape
+    raw = torch.randn(Nn, C, T, H, W, generator=g) * 1.5 + 0.3
+    gamma = torch.rand(C, generator=g) + 0.5; beta = torch.randn(C, generator=g) * 0.2
+    slope = 0.01
+    rawr = raw.double().requires_grad_(True); gr = gamma.double().requires_grad_(True); br = beta.double().requires_grad_(True)
+    a = F.leaky_relu(F.batch_norm(rawr, None, None, gr, br, True, 0.1, 1e-5), slope)
+    dA = torch.randn(a.shape, generator=g)
+    a.backward(dA.double())
+    rawg = cl(raw).to(DEV)
+    rows = Nn * T * H * W
+    flat = rawg.view(rows, -1).double()
+    part = torch.stack([flat.sum(0), (flat ** 2).sum(0)]).unsqueeze(0).float().contiguous()
+    st = ops.bn_finalize(part, C, rows, gamma.to(DEV), beta.to(DEV))
+    v = ops.view(rawg, st[2], st[3], slope)
+    dAg = cl(dA).to(DEV)
+    fused = ops.bn_backward(dAg, v, st, C, fused_finalize=True)
+    plain = ops.bn_backward(dAg, v, st, C, fused_finalize=False)
+    torch.cuda.synchronize()
+    assert ops.N.lib().md_bn_bwd_blocks(rows, C) <= 256
+    for f, p_ in zip((fused[0], fused[2], fused[3]), (plain[0], plain[2], plain[3])):
+        assert relerr(f.cpu(), p_.cpu()) < 1e-6
+    assert relerr(uncl(fused[0].cpu(), C), rawr.grad.float()) < 5e-5
+    assert relerr(fused[2].cpu(), gr.grad.float()) < 2e-5 and relerr(fused[3].cpu(), br.grad.float()) < 2e-5
+
+
 @pytest.mark.parametrize("skip_is_view", [False, True])
 def test_residual_close_forward_backward(skip_is_view):
     g = torch.Generator().manual_seed(5)

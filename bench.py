@@ -191,6 +191,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    rccl_messages = None
+    if reducer is not None:
+        # one extra untimed step with the reducer's message log on: the collectives of a step (tag, bytes) go to stderr next to the
+        # JSON line, so that a scaling record can be read against DESIGN section 7 ("5 + 1 + 1" messages)
+        reducer.log_messages = True; reducer.messages = []
+        step()
+        rccl_messages = list(reducer.messages)
+        reducer.log_messages = False
     plan = model.res2plus1d._plans[(B_PER_GPU, T, S, S)]
     # Kernel durations for the roofline object come from HIP events around every conv launch.  Bracketing every launch of
     # every step costs ~8 % of the step (measured: 1137 vs 1231 clips/s), so the timed region samples every
@@ -248,16 +256,17 @@ def main():
     if rank == 0:
         clips = B_PER_GPU * world * args.steps
         value = clips / dt
-        names = ["k_conv_patch|k_conv_pers<fp16 split>(forward)", "k_conv_patch|k_conv_pers<bf16 split>(data-gradient)", "k_wgrad_patch(+reduce)"]
+        names = ["k_conv_patch|k_conv_pers<fp16 split>(forward)", "k_conv_patch|k_conv_pers<bf16 split>(data-gradient)",
+                 "k_wgrad2|k_wgrad_patch (slab kernels; the batched slab reduction is one more launch per step)"]
         kern = []
         for (ms, n, fl), nm in zip(prof, names):
             if n:
                 kern.append({"kernel": nm, "launches": int(n), "avg_ms": ms / n, "total_ms_per_step": ms / max(1, sampled[0]),
                              "tflops": fl / (ms * 1e-3) / 1e12})
         # Dominant kernel family = the one carrying most of the algorithmic work.  Forward + data-gradient launches are the
-        # same kernel template (k_conv_patch, 2/3 of the FLOPs) and sit on the critical path; the weight gradients
-        # (k_wgrad_patch, 1/3) run on a side stream concurrently with them, so event durations of the two families overlap
-        # and "largest summed duration" would no longer identify the kernel that bounds the step.
+        # same kernel template (k_conv_patch / k_conv_pers, 2/3 of the FLOPs); the weight gradients (k_wgrad2, 1/3) run on the
+        # same stream since round 3 (one-stream schedule), so the family with the most algorithmic work is also the one
+        # with the largest summed duration.
         g_ms = prof[0][0] + prof[1][0]; g_n = prof[0][1] + prof[1][1]; g_fl = prof[0][2] + prof[1][2]
         w_ms, w_n, w_fl = prof[2]
         if g_fl >= w_fl:
@@ -301,6 +310,10 @@ def main():
                            "hbm_frac_of_8TBs": round(step_gbs / PEAK_HBM_GBS, 4)},
             "step_trace": step_trace,
         }
+        if rccl_messages is not None:
+            out["rccl_messages_per_step"] = {"count": len(rccl_messages), "bytes": int(sum(b for _, b in rccl_messages)),
+                                             "list": [[t, int(b)] for t, b in rccl_messages]}
+            print("bench | collectives of one step (rank 0): " + ", ".join("%s %d B" % (t, b) for t, b in rccl_messages), file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         if saved_stdout is not None:

@@ -5,7 +5,7 @@
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
-template <int MODE>     // 0 swish forward, 1 swish backward, 2 add noise
+template <int MODE>     // 0 swish forward, 1 swish backward, 2 add noise, 3 leaky(a + b, p0), 4 its backward (a = output, b = dout)
 __global__ __launch_bounds__(256) void k_elem(const float* __restrict__ a, const float* __restrict__ b, float p0, float p1,
                                               int64_t n, float* __restrict__ out) {
   const int64_t stride = (int64_t)gridDim.x * 256 * 4;
@@ -23,7 +23,9 @@ __global__ __launch_bounds__(256) void k_elem(const float* __restrict__ a, const
     for (int e = 0; e < 4; ++e) {
       if (MODE == 0) r[e] = x[e] * sigmoidf_(x[e]);
       else if (MODE == 1) { const float s = sigmoidf_(x[e]); r[e] = y[e] * (s * (1.f + x[e] * (1.f - s))); }
-      else r[e] = x[e] + (p0 + y[e] * p1);
+      else if (MODE == 2) r[e] = x[e] + (p0 + y[e] * p1);
+      else if (MODE == 3) r[e] = md_leaky(x[e] + y[e], p0);
+      else r[e] = y[e] * (x[e] > 0.f ? 1.f : p0);
     }
     if (full) *(float4*)(out + i) = make_float4(r[0], r[1], r[2], r[3]);
     else for (int e = 0; e < 4; ++e) if (i + e < n) out[i + e] = r[e];
@@ -48,6 +50,22 @@ extern "C" int md_swish_bwd(const float* x, const float* dy, int64_t n, float* d
   if (!x || !dy || !dx) return MD_ERR_NULL;
   if (n <= 0) return MD_ERR_BAD_SHAPE;
   MD_KLAUNCH(k_elem<1>, dim3(elem_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, dy, 0.f, 0.f, n, dx);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+// leaky(a + b, alpha): the residual close of a stand-alone SpatioTemporalResBlock (reference R2Plus1D.py:183-187); the backward takes
+// the OUTPUT (its sign is the sign of a + b for alpha >= 0) and gives the one gradient both summands share.
+extern "C" int md_add_leaky_fwd(const float* a, const float* b, float alpha, int64_t n, float* out, void* stream) {
+  if (!a || !b || !out) return MD_ERR_NULL;
+  if (n <= 0) return MD_ERR_BAD_SHAPE;
+  MD_KLAUNCH(k_elem<3>, dim3(elem_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, alpha, 0.f, n, out);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+extern "C" int md_add_leaky_bwd(const float* out, const float* dout, float alpha, int64_t n, float* dx, void* stream) {
+  if (!out || !dout || !dx) return MD_ERR_NULL;
+  if (n <= 0) return MD_ERR_BAD_SHAPE;
+  MD_KLAUNCH(k_elem<4>, dim3(elem_blocks(n)), dim3(256), 0, (hipStream_t)stream, out, dout, alpha, 0.f, n, dx);
   MD_CHECK_LAUNCH();
   return MD_OK;
 }

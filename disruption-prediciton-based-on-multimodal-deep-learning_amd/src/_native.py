@@ -106,6 +106,8 @@ SIGNATURES = {
     "md_se_scale_bwd": (C.c_int, [_P, _P, _I32, _I32, C.c_int64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "md_mask_scale": (C.c_int, [_P, _P, _F, C.c_int64, _P, _P]),
     "md_add_relu_fwd": (C.c_int, [_P, _P, C.c_int64, _P, _P]),
+    "md_add_leaky_fwd": (C.c_int, [_P, _P, _F, _I64, _P, _P]),
+    "md_add_leaky_bwd": (C.c_int, [_P, _P, _F, _I64, _P, _P]),
     "md_add_relu_bwd": (C.c_int, [_P, _P, C.c_int64, _P, _P]),
     "md_maxpool_1x3x3_fwd": (C.c_int, [_P, C.c_int64, _I32, _I32, _P, _P, _P]),
     "md_maxpool_1x3x3_bwd": (C.c_int, [_P, _P, C.c_int64, _I32, _I32, _P, _P]),

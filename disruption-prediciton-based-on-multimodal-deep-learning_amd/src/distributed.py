@@ -11,10 +11,11 @@ Exchange design for RCCL over xGMI (point-to-point links, small latency-bound me
     residual stage its weight slice is all-reduced (AVG) asynchronously on RCCL's stream while the earlier stages'
     backward kernels keep the compute stream busy -- 5 messages of 0.1-3 MB instead of 201 tiny ones;
   * BatchNorm gammas/betas (one contiguous tail of the same buffer) go in one message; every other gradient (head,
-    other encoders) lives in ONE pre-flattened bucket whose last element is the rank's "loss is finite" flag, so the
-    non-finite-loss decision (reference src/train.py:56-58) rides on that all-reduce: collective, decided on the device
-    (the optimizer kernel skips unless the averaged flag is exactly 1), and no rank skips a collective the others wait in;
-    the step contains no host synchronisation;
+    other encoders) lives in ONE pre-flattened bucket whose last element is the rank's "loss is NOT finite" indicator (0 / 1),
+    so the non-finite-loss decision (reference src/train.py:56-58) rides on that all-reduce: collective, decided on the device
+    (the update is applied iff the reduced indicator is exactly 0 -- a sum or average of zeros is exact for every world size,
+    reduction order and algorithm, which an average of ones is not: 1/3 + 1/3 + 1/3 need not round to 1), and no rank skips a
+    collective the others wait in; the step contains no host synchronisation;
   * BatchNorm statistics stay per rank (the reference has no SyncBN); parameters and buffers are broadcast from
     rank 0 once.
 """
@@ -57,9 +58,14 @@ class GradAllReducer:
     """Averages gradients across ranks.  With an R(2+1)D trunk inside `module`, the trunk's weight gradients are
     reduced stage by stage during backward (see module docstring).  Every other parameter's gradient lives in ONE
     pre-flattened bucket (``p.grad`` are views into it, so autograd accumulates straight into the bucket: no cat, no copy back)
-    whose last element carries the rank's "loss is finite" flag; one all-reduce(AVG) after backward averages the gradients and
-    -- since an average of 0/1 flags is exactly 1 only if every rank said 1 -- decides the reference's non-finite skip
-    (src/train.py:56-58) collectively and on the device."""
+    whose last element carries the rank's "loss is not finite" indicator; one all-reduce(AVG) after backward averages the
+    gradients and -- since a sum or average of 0/1 indicators is exactly 0 only if every rank said 0 -- decides the reference's
+    non-finite skip (src/train.py:56-58) collectively and on the device.
+
+    Deviation from ``optimizer.zero_grad()`` + AdamW (documented, tests/test_dp_cpu.py): a parameter outside the trunk that
+    takes no part in a step (an unused encoder of a fusion model) keeps a ZERO gradient slice here instead of ``None``, so AdamW
+    still applies weight decay and moment decay to it; the reference's loop would skip it.  Freeze such parameters
+    (``requires_grad_(False)``) to keep them out of the bucket."""
 
     def __init__(self, module: torch.nn.Module, group=None):
         self.module = module
@@ -67,6 +73,8 @@ class GradAllReducer:
         self.world = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
         self.pending: List = []
+        self.log_messages = False       # bench / tests: record (tag, bytes) of every collective of a step in self.messages
+        self.messages: List = []
         self.trunk = None
         self._trunk_param_ids = set()
         for m in module.modules():
@@ -90,14 +98,16 @@ class GradAllReducer:
         self._native_avg = False
         if self.backend == "nccl":
             try:
-                probe = torch.ones(1, device=dev)
+                probe = torch.zeros(1, device=dev)
                 dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=group)
-                self._native_avg = bool(probe.item() == 1.0)
+                self._native_avg = bool(probe.item() == 0.0)
             except Exception:
                 self._native_avg = False
 
     # -- helpers
-    def _avg(self, t: torch.Tensor, async_op: bool):
+    def _avg(self, t: torch.Tensor, async_op: bool, tag: str = ""):
+        if self.log_messages:
+            self.messages.append((tag, t.numel() * t.element_size()))
         if self._native_avg:
             return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
         w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
@@ -151,30 +161,30 @@ class GradAllReducer:
         a, b = self._stage_slices[st]
         if stream is not None:
             with torch.cuda.stream(stream):
-                self.pending.append(self._avg(flat[a:b], async_op=True))
+                self.pending.append(self._avg(flat[a:b], async_op=True, tag="trunk.stage%d.weights" % st))
         else:
-            self.pending.append(self._avg(flat[a:b], async_op=True))
+            self.pending.append(self._avg(flat[a:b], async_op=True, tag="trunk.stage%d.weights" % st))
         if st == 0:
-            self.pending.append(self._avg(flat[self._w_end:], async_op=True))   # all gammas and betas
+            self.pending.append(self._avg(flat[self._w_end:], async_op=True, tag="trunk.bn"))   # all gammas and betas
             for h in self.pending:
                 self._wait(h)
             self.pending = []
 
     def reduce_rest(self, finite: Optional[torch.Tensor] = None) -> torch.Tensor:
         """After loss.backward(): ONE all-reduce over the pre-flattened bucket of every gradient the trunk hook does not cover
-        (head, other encoders) plus the finite flag (``finite``: this rank's 0/1 device scalar; default 1).  Returns the reduced
-        flag (device, 1 element): exactly 1.0 iff the loss was finite on every rank."""
+        (head, other encoders) plus the indicator (``finite``: this rank's 0/1 device scalar, 1 = finite; default 1).  Returns
+        ``ok`` (device, 1 element): exactly 1.0 iff the loss was finite on every rank, else 0.0."""
         for p, v in zip(self.rest, self._views):
             if p.grad is None:                       # parameter took no part in this step: contributes zeros
                 continue
             if p.grad.data_ptr() != v.data_ptr():    # someone replaced .grad (e.g. optimizer.zero_grad(set_to_none=True)): fold it in
                 v.copy_(p.grad); p.grad = v
         if finite is None:
-            self.flag.fill_(1.0)
+            self.flag.fill_(0.0)
         else:
-            self.flag.copy_(finite.reshape(1).to(torch.float32))
-        self._avg(self.flat_rest, async_op=False)
-        return self.flag.clone()                     # (the bucket is zeroed again by the next step's zero_grad)
+            self.flag.copy_(1.0 - finite.reshape(1).to(torch.float32))      # "bad" indicator: 0 = finite
+        self._avg(self.flat_rest, async_op=False, tag="rest+flag")
+        return (self.flag == 0).to(torch.float32)    # (the bucket is zeroed again by the next step's zero_grad)
 
 
 def all_ranks_finite(loss: torch.Tensor, group=None) -> bool:

@@ -75,6 +75,29 @@ class SpatioTemporalConv(nn.Module):
         return self.temporal_conv(self.spatio_conv(x))
 
 
+class _AddLeakyFunction(torch.autograd.Function):
+    """leaky_relu(x + res, alpha) as one native launch each way (md_add_leaky_fwd / _bwd): the residual close of a block used
+    on its own (inside R2Plus1DNet the trunk executor closes blocks with md_residual_fwd on the raw tensors)."""
+
+    @staticmethod
+    def forward(ctx, a, b, alpha):
+        ops.require_cuda(a, b)
+        a = ops.f32(a).contiguous(); b = ops.f32(b).contiguous()
+        out = torch.empty_like(a)
+        N.check(N.lib().md_add_leaky_fwd(ops._p(a), ops._p(b), float(alpha), a.numel(), ops._p(out), ops._stream()), "md_add_leaky_fwd")
+        ctx.save_for_backward(out)
+        ctx.alpha = float(alpha)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (out,) = ctx.saved_tensors
+        g = ops.f32(dout).contiguous()
+        dx = torch.empty_like(out)
+        N.check(N.lib().md_add_leaky_bwd(ops._p(out), ops._p(g), ctx.alpha, out.numel(), ops._p(dx), ops._stream()), "md_add_leaky_bwd")
+        return dx, dx, None
+
+
 class SpatioTemporalResBlock(nn.Module):
     """Reference R2Plus1D.py:164-187.  NB (quirk kept): the inner SpatioTemporalConv children are built
     without ``alpha`` and therefore use LeakyReLU(0.01); only the closing activation uses ``alpha``."""
@@ -100,7 +123,7 @@ class SpatioTemporalResBlock(nn.Module):
         res = self.conv2(self.conv1(x))
         if self.downsample:
             x = self.downsample_conv(x)
-        return torch.nn.functional.leaky_relu(x + res, self.relu.negative_slope)
+        return _AddLeakyFunction.apply(x, res, self.relu.negative_slope)
 
 
 class SpatioTemporalResLayer(nn.Module):

@@ -38,6 +38,22 @@ class deferred_bn_counters:
         return False
 
 
+class immediate_bn_counters:
+    """Inside this context the counters are bumped at once even under an enclosing ``deferred_bn_counters()`` -- used while a
+    branch is captured into a HIP graph (utils/graphed.py::GraphedBranch): the increment has to be a launch inside the graph."""
+
+    def __enter__(self):
+        global _counter_depth
+        self.saved = _counter_depth
+        _counter_depth = 0
+        return self
+
+    def __exit__(self, *exc):
+        global _counter_depth
+        _counter_depth = self.saved
+        return False
+
+
 def bump_batches_tracked(bn) -> None:
     if _counter_depth > 0:
         _counter_pending.append(bn.num_batches_tracked)

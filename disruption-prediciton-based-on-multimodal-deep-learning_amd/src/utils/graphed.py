@@ -14,9 +14,58 @@ hipStreamEndCapture instead of returning an error (probed with tools/graph_captu
 `drop` captures and replays).  ``GraphedStep`` therefore runs its warm-up steps on a side stream while listening for exactly
 that warning and raises a RuntimeError that says what to delete, BEFORE anything is captured.
 """
+import gc
 from typing import Callable, Sequence
 
 import torch
+
+
+def live_graphs_reaching(params, limit: int = 200000):
+    """Structural form of the stale-graph check (it does not depend on the wording of a PyTorch warning): the names of live
+    Python-held tensors whose autograd graph still reaches the AccumulateGrad node of one of ``params`` -- i.e. a loss / output of
+    an EARLIER step that was kept.  Such a graph keeps those nodes, and the stream they were created on, alive; a capture whose
+    backward feeds them then has to synchronise with that stream (illegal inside a capture; ROCm 7.2 crashes in
+    hipStreamEndCapture).  Walks ``grad_fn.next_functions`` from every live non-leaf tensor (bounded by ``limit`` nodes)."""
+    ids = {id(q) for q in params}
+    hits, seen, budget = [], set(), limit
+    for o in gc.get_objects():
+        try:
+            if not isinstance(o, torch.Tensor) or o.grad_fn is None:
+                continue
+        except Exception:          # (objects that raise on attribute access: not ours)
+            continue
+        stack = [o.grad_fn]
+        found = False
+        while stack and budget > 0 and not found:
+            f = stack.pop()
+            if f is None or f in seen:
+                continue
+            seen.add(f); budget -= 1
+            if type(f).__name__ == "AccumulateGrad" and id(getattr(f, "variable", None)) in ids:
+                found = True
+                break
+            stack.extend(nf for nf, _ in f.next_functions)
+        if found:
+            hits.append("%s%s" % (type(o).__name__, tuple(o.shape)))
+    return hits
+
+
+class _rng_kept:
+    """The warm-up steps of a capture consume the CPU generator (NoiseLayer) and the device generator (dropout masks): put both
+    back afterwards, so that the first replayed step draws what the first eager step would have drawn."""
+
+    def __init__(self, device):
+        self.device = device
+
+    def __enter__(self):
+        self.cpu = torch.get_rng_state()
+        self.dev = torch.cuda.get_rng_state(self.device)
+        return self
+
+    def __exit__(self, *exc):
+        torch.set_rng_state(self.cpu)
+        torch.cuda.set_rng_state(self.dev, self.device)
+        return False
 
 
 class GraphedStep:
@@ -25,6 +74,13 @@ class GraphedStep:
         """``keep_buffers``: put the model's buffers (BatchNorm running statistics and step counters) back to their values from
         before the warm-up steps once the graph exists -- a training loop that captures on its first batch then sees exactly the
         updates an eager loop would have made."""
+        stale = live_graphs_reaching(list(model.parameters()))
+        if stale:
+            raise RuntimeError(
+                "GraphedStep: an autograd graph from an earlier training step is still alive (kept tensors: %s): its AccumulateGrad "
+                "nodes live on the stream of that step, and a capture that has to synchronise with it is illegal (on ROCm 7.2 it "
+                "segfaults in hipStreamEndCapture).  Delete or .detach() what earlier steps returned, then construct GraphedStep "
+                "again." % ", ".join(stale[:4]))
         saved_buffers = [b.detach().clone() for b in model.buffers()] if keep_buffers else None
         # NoiseLayers draw from the CPU generator: switched to one pinned staging buffer each, which the captured upload reads on
         # every replay and __call__ refills beforehand
@@ -44,7 +100,7 @@ class GraphedStep:
         warn_always = torch.is_warn_always_enabled()
         torch.set_warn_always(True)                        # the autograd warning below is a warn-once: make it observable every time
         try:
-            with warnings.catch_warnings(record=True) as caught:
+            with warnings.catch_warnings(record=True) as caught, _rng_kept(example_inputs[0].device):
                 warnings.simplefilter("always")
                 with torch.cuda.stream(side):              # warm-up off the default stream: builds plans, fills the allocator
                     for _ in range(max(1, warmup)):
@@ -201,8 +257,23 @@ class GraphedBranch:
         wrap = GraphedBranch._Wrap(owner, fn)
         wrap.train(owner.training)
         samples = tuple(t.detach().clone() for t in example_inputs)
-        self._refuse_stale_graphs(owner, wrap, samples)
-        self.call = torch.cuda.make_graphed_callables(wrap, samples)
+        stale = live_graphs_reaching([p for p in owner.parameters() if p.requires_grad])
+        if stale:
+            raise RuntimeError("GraphedBranch: an autograd graph from an earlier step is still alive (kept tensors: %s); delete or "
+                               ".detach() it before the branch is captured" % ", ".join(stale[:4]))
+        # The probe below and the warm-up iterations of make_graphed_callables run the branch in training mode: BatchNorm running
+        # statistics and step counters are put back afterwards, and so are the random generators (the branch then sees exactly the
+        # updates and draws of the eager loop).  The BatchNorm step counters are bumped INSIDE the branch while it is probed and
+        # captured (not collected for the model-level _foreach_add_), so that the "+= 1" launches are part of the forward graph
+        # and every replay advances them.
+        from ..models import _unit
+        saved_buffers = [b.detach().clone() for b in owner.buffers()]
+        with _rng_kept(samples[0].device), _unit.immediate_bn_counters():
+            self._refuse_stale_graphs(owner, wrap, samples)
+            self.call = torch.cuda.make_graphed_callables(wrap, samples)
+        with torch.no_grad():
+            for b, v in zip(owner.buffers(), saved_buffers):
+                b.copy_(v)
 
     @staticmethod
     def _refuse_stale_graphs(owner, wrap, samples):

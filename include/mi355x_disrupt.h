@@ -266,6 +266,10 @@ int md_se_scale_bwd(const float* a, const float* dout, int32_t N, int32_t C, int
 int md_mask_scale(const float* x, const float* mask, float scale, int64_t n, float* out, void* stream);
 /* Residual close of Bottleneck3D (resnet.py:196-198): out = relu(a + b); dx = dout * (out > 0) for both inputs. */
 int md_add_relu_fwd(const float* a, const float* b, int64_t n, float* out, void* stream);
+/* leaky_relu(a + b, alpha) and its backward from the OUTPUT (alpha >= 0): residual close of a stand-alone
+ * SpatioTemporalResBlock, R2Plus1D.py:183-187 (inside the trunk executor md_residual_fwd does this on the raw tensors). */
+int md_add_leaky_fwd(const float* a, const float* b, float alpha, int64_t n, float* out, void* stream);
+int md_add_leaky_bwd(const float* out, const float* dout, float alpha, int64_t n, float* dx, void* stream);
 int md_add_relu_bwd(const float* out, const float* dout, int64_t n, float* dx, void* stream);
 /* MaxPool3d(kernel (1,3,3), stride (1,2,2), padding (0,1,1)) of ResNet3D.layer0 (resnet.py:225) on `planes` = N*C*T
  * planes of H x W; idx keeps the flat h*W+w of the maximum (first one wins, NaN propagates, as ATen); the backward sums

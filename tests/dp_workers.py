@@ -105,6 +105,52 @@ def cpu_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def hardening_worker(rank, world, port, out_dir):
+    """World 3 / 4 over gloo: (1) the collective skip decision with the "not finite" indicator is exact at a world size that is
+    not a power of two; (2) a padded last batch (DistributedSampler repeats samples to fill the ranks) and a rank whose shard holds
+    no positive label still issue the SAME list of collectives, in the same order and with the same sizes, on every rank;
+    (3) a parameter that takes no part keeps a zero gradient (documented deviation)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from torch.utils.data import DataLoader
+    from torch.utils.data.distributed import DistributedSampler
+    from src.distributed import GradAllReducer, broadcast_module_state, dp_train_step
+    torch.manual_seed(300 + rank)
+    model = torch.nn.Sequential(FakeTrunk(), torch.nn.Linear(2, 2))
+    unused = torch.nn.Linear(3, 3)                          # registered, never called
+    model.add_module("unused", unused)
+    model.forward = lambda x: model[1](model[0](x))
+    broadcast_module_state(model, 0)
+    red = GradAllReducer(model)
+    red.log_messages = True
+    opt = torch.optim.SGD(model.parameters(), lr=0.05)
+    loss_fn = lambda o, t: torch.nn.functional.cross_entropy(o, t, reduction="sum")
+    # 10 samples over `world` ranks, batch 2: the sampler pads to a multiple of the world size; labels are positive only for
+    # indices that rank 0 never draws without shuffling (index % world == 0 -> label 0)
+    n = 10
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(n, 5, generator=g)
+    Y = torch.tensor([0 if i % world == 0 else 1 for i in range(n)])
+    ds = torch.utils.data.TensorDataset(X, Y)
+    sampler = DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=False)
+    loader = DataLoader(ds, batch_size=2, sampler=sampler)
+    seen, oks, msgs = [], [], []
+    for step, (x, y) in enumerate(loader):
+        if step == 1 and rank == world - 1:
+            x = x.clone(); x[0, 0] = float("nan")          # one rank's loss is not finite on step 1
+        red.messages = []
+        before = [p.detach().clone() for p in model.parameters()]
+        _, _, ok = dp_train_step(model, red, opt, loss_fn, x, y, max_norm_grad=None)
+        oks.append(float(ok.item()))
+        msgs.append(list(red.messages))
+        seen.append((y.tolist(), all(torch.equal(a, p.detach()) for a, p in zip(before, model.parameters()))))
+    torch.save({"oks": oks, "msgs": msgs, "seen": seen, "params": [p.detach().clone() for p in model.parameters()],
+                "unused_grad_zero": bool(unused.weight.grad is not None and float(unused.weight.grad.abs().sum()) == 0.0),
+                "nsamples": len(sampler)}, os.path.join(out_dir, f"hard_rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def gpu_worker(rank, world, port, out_dir):
     """Real trunk on the GPU (both ranks share cuda:0), gradients exchanged over gloo: checks the stage-hook /
     flat-buffer protocol of _plan.TrunkFunction end to end against the mean of per-shard gradients."""

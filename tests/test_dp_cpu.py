@@ -32,6 +32,34 @@ def test_grad_allreduce_world2_gloo():
     assert r0["finite_all"] is False and r1["finite_all"] is False      # one NaN rank stops every rank
 
 
+import pytest
+
+
+@pytest.mark.parametrize("world", [3, 4])
+def test_dp_hardening_padded_batches_and_exact_skip(world):
+    """VERDICT r02 next #6 / ADVICE: world sizes 3 (not a power of two: an AVERAGE of ones need not be 1, a sum of zeros is 0) and
+    4, 10 samples in batches of 2 (DistributedSampler pads the index list to a multiple of the world), rank 0 never sees a
+    positive label, one rank's loss is NaN on step 1: every rank issues the same collectives (tags and bytes) in the same order at
+    every step, the NaN step is skipped by ALL ranks and only that one, replicas stay bit-identical, an unused parameter keeps a
+    zero gradient."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(dp_workers.hardening_worker, args=(world, _free_port(), d), nprocs=world, join=True)
+        rs = [torch.load(os.path.join(d, f"hard_rank{r}.pt"), weights_only=True) for r in range(world)]
+    nsteps = len(rs[0]["oks"])
+    assert all(r["nsamples"] == -(-10 // world) for r in rs) and nsteps == -(-rs[0]["nsamples"] // 2)
+    for r in rs:
+        assert r["oks"] == [1.0 if s != 1 else 0.0 for s in range(nsteps)]              # exact, on every rank
+        assert r["msgs"] == rs[0]["msgs"]                                                # same collectives, same order, same bytes
+        assert all(unchanged == (s == 1) for s, (_, unchanged) in enumerate(r["seen"]))  # only the NaN step left the parameters alone
+        assert r["unused_grad_zero"]
+        for p, q in zip(r["params"], rs[0]["params"]):
+            assert torch.equal(p, q)
+    tags = [t for t, _ in rs[0]["msgs"][0]]
+    assert tags == ["trunk.stage4.weights", "trunk.stage3.weights", "trunk.stage2.weights", "trunk.stage1.weights",
+                    "trunk.stage0.weights", "trunk.bn", "rest+flag"]                     # DESIGN section 7: 5 + 1 + 1 messages
+    assert all(y == 0 for ys, _ in rs[0]["seen"] for y in ys)                            # rank 0 drew no positive label
+
+
 def test_train_per_proc_end_to_end_world2_gloo():
     """The mirrored entry points of the reference's src/distributed.py:29-213 actually run: two ranks, three epochs, batch 4 over
     24 training samples.  Checked: rank r sees samples r::2 of each epoch's permutation (disjoint, complete, reshuffled by

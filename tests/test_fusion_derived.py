@@ -241,14 +241,21 @@ def test_graphed_0d_branch_matches_the_eager_step():
                 torch.cuda.synchronize()
                 res.append(([o.detach().clone() for o in outs], {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}))
             used = m.__dict__.get("_md_ts_graph")
+            state = {k: v.detach().clone() for k, v in m.state_dict().items()}
         finally:
             fu._GRAPH_BRANCH = old
             m.__dict__.pop("_md_ts_graph", None)
-        return res, used
+        return res, used, state
 
-    ref, used0 = run(False)
-    got, used1 = run(True)
+    ref, used0, st0 = run(False)
+    got, used1, st1 = run(True)
     assert used0 is None and used1 not in (None, False)
+    # buffers too: the probe and the warm-up iterations of the capture must not leave extra BatchNorm momentum updates behind, and
+    # the replays must advance num_batches_tracked exactly as the eager steps do (graphed.py)
+    assert st0.keys() == st1.keys()
+    for k in st0:
+        assert torch.equal(st0[k], st1[k]), k
+    assert any(k.endswith("num_batches_tracked") and int(v) == 3 for k, v in st1.items() if k.startswith("ts_model."))
     for (o0, g0), (o1, g1) in zip(ref, got):
         for a, b in zip(o0, o1):
             assert torch.equal(a, b)

@@ -91,6 +91,44 @@ def test_baseline_cfg3_shape_runs():
 
 
 @pytest.mark.gpu
+def test_baseline_cfg3_against_the_oracle():
+    """BASELINE.json configs[2] at its real size (B=4, T=21, 3, 224, 224; patch 16, dim 128, depth 2, heads 4, d_head 64,
+    scale_dim 8, pool mean), dropout 0: logits within 1e-3 and EVERY parameter gradient within 3e-3 relative L2 of
+    oracle/vivit.py on the CPU (fp32) from the same weights -- the gather-GEMM patch embedding, the log-sum-exp attention at
+    197 tokens and the eight-wave Linear kernels end to end (reference src/models/ViViT.py:141-223)."""
+    from src.models.ViViT import ViViT
+    torch.set_num_threads(16)
+    torch.manual_seed(3)
+    m = ViViT(image_size=224, patch_size=16, n_frames=21, n_classes=2, dim=128, depth=2, n_heads=4, pool="mean", in_channels=3,
+              d_head=64, dropout=0.0, embedd_dropout=0.0, scale_dim=8)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(4, 3, 21, 224, 224, generator=g)
+    dl = torch.tensor([[0.4, -0.6], [-0.3, 0.2], [0.5, 0.1], [-0.2, -0.4]])
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = ov.vivit_forward(x, leaves, 16, 2, 4, "mean", 3, 1.0, with_mlp=True)
+    (ref * dl).sum().backward()
+    m = m.cuda().train()
+    out = m(x.cuda())
+    out.backward(dl.cuda())
+    torch.cuda.synchronize()
+    assert float((out.detach().cpu() - ref.detach()).abs().max()) <= 1e-3 * max(1.0, float(ref.detach().abs().max()))
+    worst, checked = (0.0, ""), 0
+    for k, p in m.named_parameters():
+        r = leaves[k].grad
+        assert p.grad is not None and r is not None, k
+        e = _relerr(p.grad.cpu(), r)
+        worst = max(worst, (e, k))
+        assert e < 3e-3, (k, e)
+        checked += 1
+    assert checked >= 10
+    for must in ("to_patch_embedding.1.weight", "pos_embedding", "space_transformer.layers.0.0.fn.to_qkv.weight",
+                 "space_transformer.layers.0.1.fn.net.0.weight", "space_transformer.layers.0.1.fn.net.3.weight"):
+        assert must in leaves, must
+    print("cfg3 full size: worst parameter-gradient relative L2 %.2e (%s) over %d tensors" % (worst[0], worst[1], checked))
+
+
+@pytest.mark.gpu
 def test_elu_and_residual_layernorm_match_torch():
     from src.models._unit import EluFunction, ResidualLayerNormFunction
     torch.manual_seed(9)

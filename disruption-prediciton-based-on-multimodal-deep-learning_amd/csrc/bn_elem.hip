@@ -469,10 +469,11 @@ extern "C" int md_residual_fwd(const MdActView* skip, const MdActView* main, flo
   return MD_OK;
 }
 
-// Geometry of the BatchNorm-backward passes: at most 256 workgroups (= partial rows, so that the apply pass can sum them in its
-// prologue); 256 threads each while 16 rows per row lane are enough for that, 1024 threads for the large tensors.
+// Geometry of the BatchNorm-backward reduction: up to MD_BN_RED_CAP (2048) workgroups of 256 threads, 16 rows per row lane; past
+// the cap, 1024-thread workgroups.  (A cap of 256 -- few partial rows, for md_bn_bwd_apply_fused -- measured 0.06 ms per step
+// slower on the R(2+1)D bench, profiles/r03_bn_fused_finalize.txt.)
 static int bn_pass_geom(int64_t rows, int C4, int per, int* nth) {
-  static const int cap = getenv("MD_BN_RED_CAP") ? atoi(getenv("MD_BN_RED_CAP")) : 256;
+  static const int cap = getenv("MD_BN_RED_CAP") ? atoi(getenv("MD_BN_RED_CAP")) : 2048;
   int64_t b = md_cdiv64(rows, (int64_t)(256 / C4) * per);
   *nth = 256;
   if (b > cap) { *nth = 1024; b = md_cdiv64(rows, (int64_t)(1024 / C4) * per); }
@@ -533,7 +534,7 @@ extern "C" int md_bn_bwd_apply(const float* dA, const MdActView* main, const MdA
   return MD_OK;
 }
 
-// Finalize + apply in one launch (fp32 d_raw): the apply pass sums the `blocks` (<= 256) partial rows of the reduction pass -- or of
+// Finalize + apply in one launch (fp32 d_raw): the apply pass sums the `blocks` partial rows of the reduction pass -- or of
 // a data gradient's fused reduction, g_in != 0 -- itself and writes dgamma / dbeta; no coefficient buffer, no finalize launch.
 extern "C" int md_bn_bwd_apply_fused(const float* dA, int g_in, const MdActView* main, const MdActView* skip, float alpha,
                                      const float* mean, const float* invstd, const float* partial, int32_t blocks, int64_t count,
@@ -541,7 +542,7 @@ extern "C" int md_bn_bwd_apply_fused(const float* dA, int g_in, const MdActView*
   if (!dA || !main || !main->data || !mean || !invstd || !partial || !d_raw) return MD_ERR_NULL;
   if (skip != nullptr && !dS) return MD_ERR_NULL;
   if (g_in && (skip != nullptr || !main->scale)) return MD_ERR_UNSUPPORTED;
-  if (blocks <= 0 || blocks > 256 || count <= 0) return MD_ERR_BAD_SHAPE;
+  if (blocks <= 0 || count <= 0) return MD_ERR_BAD_SHAPE;
   int rc = check_rows(rows, C); if (rc) return rc;
   const int C4 = md_cpad(C) / 4;
   // geometry of the plain apply pass (many 256-thread workgroups: the streaming part measured 14 % slower as 256 workgroups of

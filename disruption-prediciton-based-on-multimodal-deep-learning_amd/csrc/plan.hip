@@ -543,7 +543,7 @@ static int unit_backward(MdPlan* P, float* ws, int ui, int gb, int dxb, int accu
     MdActView mainv = unit_out_view(P, ws, ui);
     // (fused_fin: the apply pass sums the <= 256 partial rows itself -- no finalize launch between the two passes)
     const int rb = P->red_blocks[ui];
-    const bool fused_fin = bn_fused_fin() && !u.split && rb <= 256;
+    const bool fused_fin = bn_fused_fin() && !u.split;
     if (rb > 0) {
       // the consumer's data gradient already reduced: G holds g, the partial buffer its sums
       if (fused_fin) {

@@ -176,7 +176,7 @@ int md_conv_split_dy_ok(const MdConvDesc* d, int need_dgrad);
 int md_bn_bwd_apply_fmt(const float* dA, int g_in, const MdActView* main, const MdActView* skip, float alpha,
                         const float* mean, const float* invstd, const float* coef, int64_t rows, int32_t C,
                         void* d_raw, int split_out, float* dS, void* stream);
-/* Finalize + apply in one launch (fp32 d_raw): the apply pass itself sums the `blocks` (<= 256) partial rows written by
+/* Finalize + apply in one launch (fp32 d_raw): the apply pass itself sums the `blocks` partial rows written by
  * md_bn_bwd_reduce -- or, with g_in != 0, by a data gradient's fused reduction (dA then holds g) -- in fp64 and a fixed order,
  * writes dgamma / dbeta (either may be NULL) and d_raw (and dS with a skip view); replaces md_bn_bwd_finalize +
  * md_bn_bwd_apply[_g] and their coefficient buffer.  count = rows.  Backward of R2Plus1D.py:53-58, :179-187. */

@@ -76,11 +76,17 @@ __device__ __forceinline__ void stage_image(__amdgpu_buffer_rsrc_t src, int Cpit
 // F16 = false: data gradient, operands split into bf16 halves (gradients need bf16's exponent range).
 // W8: eight waves (512 threads) on the same 128-pixel box -- wave = (row pair wr, column half wc); used where LDS allows
 // only one workgroup per CU, so that two waves per SIMD can overlap each other's staging, LDS and matrix phases.
-template <bool F16, bool STRIDED, int NREP, bool W8 = false>
+// HALF (round 3): four waves on a 64-pixel box -- wave = (row pair wr of two, column half wc): the box and its patch are half the
+// size, so the layers whose 128-pixel form fills the LDS of a CU (one workgroup, nothing overlaps its staging) run two workgroups
+// per CU, and the deep layers with fewer boxes than CUs spread over twice as many workgroups.
+template <bool F16, bool STRIDED, int NREP, bool W8 = false, bool HALF = false>
 __global__ __launch_bounds__(W8 ? 512 : 256) void k_conv_patch(
     PGeom g, const float* __restrict__ src, const float* __restrict__ pscale, const float* __restrict__ pshift,
     float pslope, const uint4* __restrict__ wp, float* __restrict__ dst, float* __restrict__ stat_partial,
-    int accumulate, int n_per_blk) {
+    int accumulate, int n_per_blk, PersBwd bw) {
+  // bw.yraw != nullptr (data gradient only): fused BatchNorm-backward reduction of the unit this gradient feeds, as in
+  // k_conv_pers -- the epilogue reads that unit's raw output at the pixels it has just produced, stores
+  // g = dA * leaky'(bn(y)) instead of dA and writes sum(g), sum(g * xhat) per channel as this box's partial row.
   extern __shared__ __attribute__((aligned(16))) char sm[];
   char* sP = sm;                                   // patch hi | lo
   char* sB = sm + g.off_b;                         // B tile hi [n][160 B] | lo
@@ -92,9 +98,12 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void k_conv_patch(
 
   const int t = threadIdx.x;
   constexpr int NT = W8 ? 512 : 256;
-  constexpr int NW = W8 ? (NREP + 1) / 2 : NREP;          // column tiles per wave
+  static_assert(!(W8 && HALF), "one wave layout");
+  constexpr bool SPLITC = W8 || HALF;                     // the waves of a row pair split the column tiles
+  constexpr int RG = HALF ? 2 : 4;                        // row pairs (32 rows each) of the box
+  constexpr int NW = SPLITC ? (NREP + 1) / 2 : NREP;      // column tiles per wave
   const int lane = t & 63, wave = t >> 6;
-  const int wr = wave & 3, wc = wave >> 2;                // rows 32*wr .. +31; column half (W8 only)
+  const int wr = wave & (RG - 1), wc = wave / RG;         // rows 32*wr .. +31; column half (W8 / HALF only)
   const int j0 = wc ? NREP - NW : 0;                      // first column tile of this wave (odd NREP: the halves overlap by one)
   const int li = lane & 15, lg = lane >> 4;
   const int n0 = blockIdx.y * n_per_blk;
@@ -132,7 +141,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void k_conv_patch(
     const bool v = ((unsigned)st < (unsigned)g.Ts) && ((unsigned)sy < (unsigned)g.Hs) && ((unsigned)sx < (unsigned)g.Ws);
     sG[p] = v ? ((n * g.Ts + st) * g.Hs + sy) * g.Ws + sx : -1;
   }
-  if (t < PM) {
+  if (t < 32 * RG) {
     const int rt = mdiv(t, g.m_byx); const int r = t - rt * g.byx;
     const int ry = mdiv(r, g.m_bx); const int rx = r - ry * g.bx;
     const bool v = (rt < g.bt) && (t0 + rt < g.Td) && (y0 + ry < g.Hd) && (x0 + rx < g.Wd);
@@ -295,10 +304,12 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void k_conv_patch(
   __syncthreads();
   float* red = (float*)sP;   // [4 waves][2][PNREP*16]
   const __amdgpu_buffer_rsrc_t drs = make_rsrc(dst, (dbg & 4) ? 0u : g.dst_bytes);
+  const bool fuse = !F16 && bw.yraw != nullptr;                  // wave-uniform
+  const __amdgpu_buffer_rsrc_t yrs = make_rsrc(fuse ? bw.yraw : dst, g.dst_bytes);
 #pragma unroll
   for (int j = 0; j < NW; ++j) {
     // (W8, odd NREP: the second half's first tile is also the first half's last -- computed twice, written and counted once)
-    const bool dup = W8 && (NREP & 1) && wc == 1 && j == 0;
+    const bool dup = SPLITC && (NREP & 1) && wc == 1 && j == 0;
     const bool colok = !dup && n0 + (j0 + j) * 16 + li < g.Cpd;
     float s1 = 0.f, s2 = 0.f;
     float prev[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -309,15 +320,37 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void k_conv_patch(
         for (int r = 0; r < 4; ++r)
           prev[a][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, colok ? goff[a][r] : MD_OOB, j * 64, 0));
     }
+    if (fuse) {
+      const int c = n0 + (j0 + j) * 16 + li;
+      const bool cok = c < g.Cpd;
+      const float csc = cok ? bw.scale[c] : 0.f, csh = cok ? bw.shift[c] : 0.f, cmu = cok ? bw.mean[c] : 0.f, cis = cok ? bw.invstd[c] : 0.f;
+      float yv[2][4];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float v = acc[a][j][r];
-        const float vm = v * gw[a][r];
-        s1 += vm; s2 = fmaf(vm, v, s2);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v + prev[a][r]), drs, colok ? goff[a][r] : MD_OOB, j * 64, 0);
-      }
+        for (int r = 0; r < 4; ++r)
+          yv[a][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, colok ? goff[a][r] : MD_OOB, j * 64, 0));
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pre = fmaf(yv[a][r], csc, csh);
+          const float v = (acc[a][j][r] + prev[a][r]) * md_dleaky(pre, bw.slope);      // g = dA * leaky'(bn(y))
+          const float vm = v * gw[a][r];
+          s1 += vm; s2 = fmaf(vm, (yv[a][r] - cmu) * cis, s2);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), drs, colok ? goff[a][r] : MD_OOB, j * 64, 0);
+        }
+    } else {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc[a][j][r];
+          const float vm = v * gw[a][r];
+          s1 += vm; s2 = fmaf(vm, v, s2);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v + prev[a][r]), drs, colok ? goff[a][r] : MD_OOB, j * 64, 0);
+        }
+    }
     if (stat_partial != nullptr) {
       s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
       s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
@@ -332,7 +365,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void k_conv_patch(
     if (t < ncols && n0 + t < g.Cpd) {
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) {
+      for (int w = 0; w < RG; ++w) {
         s1 += red[(w * 2 + 0) * (PNREP * 16) + t];
         s2 += red[(w * 2 + 1) * (PNREP * 16) + t];
       }
@@ -370,7 +403,7 @@ struct ClassSpec { int c[3], tap0[3], kc[3], e[3]; };
 // pers_wgs > 0: geometry for the persistent kernel (conv_pers.hip) at that many workgroups per CU -- the LDS budget then
 // holds the whole packed weight operand instead of one streamed stage.
 static bool patch_build(const MdConvDesc* d, int dgrad, PGeom* out, size_t* lds_bytes, const ClassSpec* cls = nullptr,
-                        int pers_wgs = 0) {
+                        int pers_wgs = 0, int pm_rows = PM, int npb_force = 0) {
   PGeom g;
   const bool sdg = !cls && dgrad && (d->st != 1 || d->sh != 1 || d->sw != 1);      // strided data gradient, tap-test form
   g.strided = sdg ? 1 : 0;
@@ -432,10 +465,10 @@ static bool patch_build(const MdConvDesc* d, int dgrad, PGeom* out, size_t* lds_
   }
   if (g.Cps > PMAXC) return false;
   const int nchunks_ = md_cdiv(g.N16, PNREP * 16);
-  const int npb_ = md_round_up(md_cdiv(g.N16, nchunks_), 16);
+  const int npb_ = npb_force ? npb_force : md_round_up(md_cdiv(g.N16, nchunks_), 16);
   // LDS: everything but the patch
   if (pers_wgs && (sdg || g.N16 > 128 || g.N16 < 32)) return false;
-  const int pm = PM;
+  const int pm = pm_rows;
   const size_t fixed = pers_wgs ? pers_bres_bytes(g.Kc8, g.N16) + pers_fixed_bytes(g.Cps, g.N16) + (size_t)g.nstages * 8 * 4
                                 : (size_t)2 * npb_ * PB_PITCH + (size_t)g.nstages * 8 * 4 + (size_t)PM * 16 + 3072 + 2 * PMAXC * 4 + 1024;
   const size_t cap = (size_t)160 * 1024;
@@ -476,7 +509,7 @@ static bool patch_build(const MdConvDesc* d, int dgrad, PGeom* out, size_t* lds_
   if (pers_wgs && (g.pt >= 64 || g.py >= 512 || g.px >= 512 || g.bt >= 256 || g.by >= 256 || g.bx >= 256)) return false;
   if (getenv("MD_PLAN_PRINT"))
     fprintf(stderr, "patch%s %s %d->%d k%d%d%d s%d%d%d dst %dx%dx%d: box %dx%dx%d patch %dx%dx%d=%d C8=%d stages=%d lds=%zu\n",
-            pers_wgs ? "(persistent)" : "", dgrad ? (cls ? "dgrad-class" : "dgrad") : "fwd", d->Cin, d->Cout, d->kt, d->kh, d->kw, d->st, d->sh, d->sw, g.Td, g.Hd,
+            pers_wgs ? "(persistent)" : (pm_rows != PM ? "(half)" : ""), dgrad ? (cls ? "dgrad-class" : "dgrad") : "fwd", d->Cin, d->Cout, d->kt, d->kh, d->kw, d->st, d->sh, d->sw, g.Td, g.Hd,
             g.Wd, g.bt, g.by, g.bx, g.pt, g.py, g.px, g.P, g.C8, g.nstages, off);
   *out = g; *lds_bytes = off;
   return true;
@@ -487,7 +520,10 @@ static std::atomic<int> g_pers_grid{0};     // > 0: test override of the persist
 extern "C" int md_set_pers_grid(int n) { return g_pers_grid.exchange(n > 0 ? n : 0); }
 struct PersVariant { bool on; PersGeom pg; size_t lds; int grid; };           // persistent-kernel form of the same launch
 struct PatchClass { PGeom g; size_t lds; size_t wp_off; ClassSpec spec; PersVariant pers; };     // wp_off: floats into the packed operand
-struct PatchPlan { PGeom g; size_t lds; int N; int dgrad; int ncls; PatchClass cls[8]; PersVariant pers; };
+struct PatchPlan {
+  PGeom g; size_t lds; int N; int dgrad; int ncls; PatchClass cls[8]; PersVariant pers;
+  bool half; PGeom gh; size_t ldsh; int half_npb;      // 64-pixel boxes, four waves as 2 row pairs x 2 column halves (k_conv_patch HALF)
+};
 
 // Persistent form (conv_pers.hip) of one launch, when the geometry qualifies: the packed weights fit in LDS beside the
 // patch, the box is nearly full, and there are at least as many boxes as resident workgroups.  The packed-weight format
@@ -585,9 +621,35 @@ const PatchPlan* patch_lookup(const MdConvDesc* d, int dgrad) {
     if (cp->ncls > 0) { cp->g = cp->cls[0].g; cp->lds = cp->cls[0].lds; cp->N = d->N; cp->dgrad = 1; cp->pers.on = false; pp = cp; }
     else delete cp;
   }
+  if (pp) pp->half = false;
   if (!pp && patch_build(d, dgrad, &g, &lds)) {
     pp = new PatchPlan(); pp->g = g; pp->lds = lds; pp->N = d->N; pp->dgrad = dgrad; pp->ncls = 0;
     pers_try(d, dgrad, nullptr, g, &pp->pers);
+    pp->half = false;
+    // 64-pixel form: where the 128-pixel workgroup owns the CU's LDS (> 80 KB: nothing overlaps its staging) and the half-size
+    // one fits twice, or where the layer has too few boxes to fill the chip.  MD_PATCH_HALF: 0 never, 1 automatic, 2 whenever built.
+    static const int half_env = getenv("MD_PATCH_HALF") ? atoi(getenv("MD_PATCH_HALF")) : 1;
+    const bool strided_dg = dgrad && (d->st != 1 || d->sh != 1 || d->sw != 1);
+    if (half_env && !pp->pers.on && !strided_dg && g.N16 >= 32) {
+      const size_t cap2 = 80 * 1024 - 256;
+      for (int nch = 1; nch <= g.N16 / 32 && !pp->half; ++nch) {
+        const int npb = md_round_up(md_cdiv(g.N16, nch), 16);
+        if (npb > PNREP * 16 || npb < 32) continue;
+        PGeom gh; size_t ldsh = 0;
+        if (!patch_build(d, dgrad, &gh, &ldsh, nullptr, 0, 64, npb)) continue;
+        if (gh.Kc8 != g.Kc8 || gh.N16 != g.N16 || gh.nstages != g.nstages) continue;
+        if (gh.bt * gh.by * gh.bx < 48) continue;                       // mostly empty boxes: not worth it
+        if (ldsh > cap2 && nch < g.N16 / 32) continue;                  // try a narrower column group first
+        const int boxes_full = d->N * g.nbt * g.nby * g.nbx;
+        // measured (profiles/r03_patch_half.txt): splitting the columns to get under 80 KB costs more (the patch is staged once per
+        // column group) than the second workgroup per CU brings -- 64 -> 144 at 32x32: 63 -> 79 us -- so only the un-split case
+        // counts; the layers with a handful of boxes gain from the extra workgroups (128 -> 288 at 8x8: 19 -> 14 us).
+        const bool two_per_cu = nch == 1 && lds > cap2 + 256 && ldsh <= cap2;
+        const bool few_boxes = boxes_full < 64;
+        if (half_env == 2 || two_per_cu || few_boxes) { pp->half = true; pp->gh = gh; pp->ldsh = ldsh; pp->half_npb = npb; }
+        break;
+      }
+    }
   }
   cache[key] = pp;
   return pp;
@@ -681,6 +743,7 @@ size_t patch_wpack_floats(const PatchPlan* p) {      // 16-bit element count / 2
 }
 static int variant_blocks(const PatchPlan* p, const PGeom& g, const PersVariant& pv) {
   if (pv.on) return pers_blocks(pv.pg, pv.grid);
+  if (p->half && &g == &p->g) return p->N * p->gh.nbt * p->gh.nby * p->gh.nbx;
   return p->N * g.nbt * g.nby * g.nbx;
 }
 // rows of the partial-sum buffer written by one launch sequence (all residue classes)
@@ -698,6 +761,52 @@ int patch_pack(const MdConvDesc* d, int dgrad, const PatchPlan* p, const float* 
   return rc ? rc : (handled ? MD_OK : MD_ERR_UNSUPPORTED);
 }
 
+// 64-pixel form (HALF): column groups of p->half_npb channels (or narrower when the layer has few boxes)
+static PersBwd no_bwd() { PersBwd n; n.yraw = nullptr; n.scale = n.shift = n.mean = n.invstd = nullptr; n.slope = 1.f; return n; }
+static int patch_launch_half(const PatchPlan* p, const float* src, const float* ps, const float* psh, float slope, const float* wp,
+                             float* dst, float* stat, int accumulate, hipStream_t s, const PersBwd* bw) {
+  const PGeom& g = p->gh;
+  const PersBwd bwv = bw ? *bw : no_bwd();
+  if ((accumulate >> 16) & 1) { if (!p->dgrad || g.pack2) return MD_ERR_UNSUPPORTED; }
+  const int boxes = p->N * g.nbt * g.nby * g.nbx;
+  int npb = p->half_npb;
+  {   // few boxes: narrower column groups (>= 2 tiles each) until the chip is covered
+    static const int fill = getenv("MD_PATCH_FILL") ? atoi(getenv("MD_PATCH_FILL")) : 128;
+    while (npb > 32 && boxes * md_cdiv(g.N16, npb) < 2 * fill) npb = md_round_up(md_cdiv(npb, 2), 16) < 32 ? 32 : md_round_up(md_cdiv(npb, 2), 16);
+  }
+  dim3 grid(boxes, md_cdiv(g.N16, npb));
+  static const int dbg = getenv("MD_DBG") ? atoi(getenv("MD_DBG")) : 0;
+  accumulate = (accumulate & 0x10001) | ((dbg & 0xff) << 8);
+  const int nrep = npb / 16;
+  const size_t lds = p->ldsh;
+#define LAUNCH_HALF(F16_, NR_)                                                                                          \
+  do {                                                                                                                  \
+    static bool set_ = false;                                                                                           \
+    if (!set_) {                                                                                                        \
+      if (hipFuncSetAttribute((const void*)k_conv_patch<F16_, false, NR_, false, true>,                                 \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)                    \
+        return MD_ERR_LAUNCH;                                                                                           \
+      set_ = true;                                                                                                      \
+    }                                                                                                                   \
+    MD_KLAUNCH((k_conv_patch<F16_, false, NR_, false, true>), grid, dim3(256), lds, s, g, src, ps, psh, slope,          \
+               (const uint4*)wp, dst, stat, accumulate, npb, bwv);                                                      \
+  } while (0)
+#define LAUNCH_HALF_NR(F16_)                                                                                            \
+  switch (nrep) {                                                                                                       \
+    case 2: LAUNCH_HALF(F16_, 2); break;                                                                                \
+    case 3: LAUNCH_HALF(F16_, 3); break;                                                                                \
+    case 4: LAUNCH_HALF(F16_, 4); break;                                                                                \
+    case 5: LAUNCH_HALF(F16_, 5); break;                                                                                \
+    case 6: LAUNCH_HALF(F16_, 6); break;                                                                                \
+    case 7: LAUNCH_HALF(F16_, 7); break;                                                                                \
+    case 8: LAUNCH_HALF(F16_, 8); break;                                                                                \
+    default: LAUNCH_HALF(F16_, 9); break;                                                                               \
+  }
+  if (!p->dgrad) { LAUNCH_HALF_NR(true); } else { LAUNCH_HALF_NR(false); }
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+
 static int patch_launch_one(const PatchPlan* p, const PGeom& g, size_t lds, const PersVariant& pv, const float* src, const float* ps,
                             const float* psh, float slope, const float* wp, float* dst, float* stat, int accumulate,
                             const PersBwd* bw, hipStream_t s) {
@@ -707,7 +816,9 @@ static int patch_launch_one(const PatchPlan* p, const PGeom& g, size_t lds, cons
     PersBwd none; none.yraw = nullptr; none.scale = none.shift = none.mean = none.invstd = nullptr; none.slope = 1.f;
     return pers_launch(pv.pg, pv.lds, pv.grid, !p->dgrad, src, ps, psh, slope, wp, dst, stat, accumulate, bw ? *bw : none, s);
   }
-  if (bw) return MD_ERR_UNSUPPORTED;
+  if (bw && !p->dgrad) return MD_ERR_UNSUPPORTED;
+  if (p->half && &g == &p->g) return patch_launch_half(p, src, ps, psh, slope, wp, dst, stat, accumulate, s, bw);
+  const PersBwd bwv = bw ? *bw : no_bwd();
   int nchunks = md_cdiv(g.N16, PNREP * 16);
   const int boxes = p->N * g.nbt * g.nby * g.nbx;
   {   // few boxes (the deep, small layers): split the destination channels over more workgroups so every CU gets one
@@ -738,7 +849,7 @@ static int patch_launch_one(const PatchPlan* p, const PGeom& g, size_t lds, cons
       set_ = true;                                                                                                      \
     }                                                                                                                   \
     MD_KLAUNCH((k_conv_patch<F16_, STR_, NR_, W8_>), grid, dim3(W8_ ? 512 : 256), lds, s, g, src, ps, psh, slope,       \
-               (const uint4*)wp, dst, stat, accumulate, npb);                                                           \
+               (const uint4*)wp, dst, stat, accumulate, npb, bwv);                                                      \
   } while (0)
 #define LAUNCH_PATCH_NR(F16_, STR_, W8_)                                                                                \
   switch (nrep) {                                                                                                       \
@@ -763,9 +874,14 @@ static int patch_launch_one(const PatchPlan* p, const PGeom& g, size_t lds, cons
 // persistent form: patch_can_fuse); `stat` then receives patch_blocks(p) partial rows.
 bool patch_can_fuse(const PatchPlan* p) {
   if (!p->dgrad) return false;
-  // instantiated without register spills: up to 3 channel tiles (and then at most 4 staged items per thread with 3)
+  // persistent form: instantiated without register spills up to 3 channel tiles (and then at most 4 staged items per thread with 3);
+  // per-box form (k_conv_patch, round 3): any tile count -- its epilogue walks the tiles one at a time
   static const int maxn = getenv("MD_FUSE_MAXN16") ? atoi(getenv("MD_FUSE_MAXN16")) : 48;      // experiment: larger tile counts spill
-  auto ok = [](const PersVariant& pv) { return pv.on && pv.pg.g.N16 <= maxn && !(pv.pg.g.N16 == 48 && pv.pg.nit > 4) && !(pv.pg.g.N16 > 48 && pv.pg.nit > 4); };
+  static const int patch_off = getenv("MD_FUSE_PATCH") && atoi(getenv("MD_FUSE_PATCH")) == 0;
+  auto ok = [](const PersVariant& pv) {
+    if (!pv.on) return !patch_off;
+    return pv.pg.g.N16 <= maxn && !(pv.pg.g.N16 == 48 && pv.pg.nit > 4) && !(pv.pg.g.N16 > 48 && pv.pg.nit > 4);
+  };
   if (!p->ncls) return ok(p->pers);
   for (int c = 0; c < p->ncls; ++c) if (!ok(p->cls[c].pers)) return false;
   return true;

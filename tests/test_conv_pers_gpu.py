@@ -156,6 +156,60 @@ def test_fused_batchnorm_backward_reduction(case, accumulate, pers_grid):
         assert float(d_raw[..., Cin:].abs().max()) == 0.0, tag
 
 
+PATCH_FUSE_CASES = CASES + [
+    ("wide72", 72, 32, (3, 1, 1), (1, 1, 1), (1, 0, 0), (2, 6, 12, 12)),          # 5 destination tiles (the 64x64 stage's 72-channel tensors)
+    ("wide144", 144, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 5, 8, 8)),          # 9 tiles: column halves of the eight-wave form
+    ("wide115s", 115, 64, (3, 1, 1), (2, 1, 1), (1, 0, 0), (2, 9, 9, 9)),         # strided (per-tap test form), 8 tiles, Cp % 8 == 4
+    ("tiny288", 128, 288, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 3, 8, 8)),         # few boxes: the 64-pixel form
+]
+
+
+@pytest.mark.parametrize("case", [c for c in PATCH_FUSE_CASES if c[0] != "stem"], ids=[c[0] for c in PATCH_FUSE_CASES if c[0] != "stem"])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_fused_reduction_in_the_per_box_kernels(case, accumulate):
+    """Round 3: the per-box data-gradient kernels (k_conv_patch: classic, eight-wave, 64-pixel, strided and residue-class forms)
+    carry the fused BatchNorm-backward reduction too, for ANY number of destination tiles -- default grid (no persistent override),
+    so geometries without a persistent form take them.  Same references as the persistent test: autograd on the CPU and the unfused
+    kernel sequence."""
+    name, Cin, Cout, k, s, p, (Nn, T, H, W) = case
+    g = torch.Generator().manual_seed(17 + sum(map(ord, name)))
+    yP = torch.randn(Nn, Cin, T, H, W, generator=g) * 1.5 + 0.2
+    gamma = torch.rand(Cin, generator=g) + 0.5
+    beta = torch.randn(Cin, generator=g) * 0.3
+    w = torch.randn(Cout, Cin, *k, generator=g) / np.sqrt(Cin * k[0] * k[1] * k[2])
+    slope = 0.01
+    yr = yP.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True); br = beta.clone().requires_grad_(True)
+    a = F.leaky_relu(F.batch_norm(yr, None, None, gr, br, True, 0.1, 1e-5), slope)
+    out = F.conv3d(a, w, None, s, p)
+    dy = torch.randn(out.shape, generator=g)
+    extra = torch.randn(a.shape, generator=g) * 0.5 if accumulate else None
+    ((out * dy).sum() + ((a * extra).sum() if accumulate else 0.0)).backward()
+    d = ops.make_desc(Nn, T, H, W, Cin, Cout, k, s, p)
+    mean, invstd = _bn_stats(yP)
+    Cp = ops.cpad(Cin)
+    st = torch.zeros(4, Cp)
+    st[0, :Cin] = mean; st[1, :Cin] = invstd; st[2, :Cin] = gamma * invstd; st[3, :Cin] = beta - mean * gamma * invstd
+    st = st.to(DEV)
+    yg, dyg = cl(yP).to(DEV), cl(dy).to(DEV)
+    _, wd = ops.pack_weights(d, w.to(DEV))
+    yv = ops.view(yg, st[2], st[3], slope)
+    base = cl(extra).to(DEV) if accumulate else None
+    fused = ops.conv_dgrad_bnred(d, dyg, wd, yv, st, out=None if base is None else base.clone(), accumulate=accumulate)
+    assert fused is not None, name
+    gq, part = fused
+    d_raw, dgamma, dbeta = ops.bn_backward_from_g(gq, part, yv, st, Cin)
+    dA = ops.conv_dgrad(d, dyg, wd, out=None if base is None else base.clone(), accumulate=accumulate)
+    d_raw0, _, dgamma0, dbeta0 = ops.bn_backward(dA, yv, st, Cin)
+    torch.cuda.synchronize()
+    tag = (name, accumulate)
+    assert relerr(uncl(d_raw.cpu(), Cin), yr.grad) < 5e-5, tag
+    assert relerr(dgamma.cpu(), gr.grad) < 5e-5 and relerr(dbeta.cpu(), br.grad) < 5e-5, tag
+    assert relerr(d_raw, d_raw0) < 1e-5 and relerr(dgamma, dgamma0) < 1e-5 and relerr(dbeta, dbeta0) < 1e-5, tag
+    if d_raw.shape[-1] > Cin:
+        assert float(d_raw[..., Cin:].abs().max()) == 0.0, tag
+
+
 def test_trunk_with_persistent_kernels_against_the_oracle():
     """Whole R(2+1)D classifier, forward + loss + backward, on a clip large enough that the default plan picks the
     persistent kernels (and the fused reduction where it exists) for the 64x64-resolution units (448 boxes >= 2 x 128):

@@ -94,9 +94,9 @@ __global__ __launch_bounds__(256) void k_residual_fwd(View skip, View main, floa
 }
 
 // Sum the per-workgroup partial rows [blocks][2][Cp] for channels 4*blockIdx.x .. +3 in fp64: 256 row lanes (row r,
-// r+256, ...) then a fixed tree -- deterministic for a given partial buffer.  Result (8 doubles) in out[] of thread 0.
+// r+256, ...), then a fixed shuffle / LDS tree -- deterministic for a given partial buffer.  Result (8 doubles) in out[] of every thread.
 __device__ __forceinline__ void reduce_partials4(const float* __restrict__ partial, int blocks, int Cp, double out[8]) {
-  __shared__ double red[8][257];
+  __shared__ double red[4][8];
   const int r = threadIdx.x;
   const int c0 = blockIdx.x * 4;
   double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -106,18 +106,20 @@ __device__ __forceinline__ void reduce_partials4(const float* __restrict__ parti
     a[0] += s1.x; a[1] += s1.y; a[2] += s1.z; a[3] += s1.w;
     a[4] += s2.x; a[5] += s2.y; a[6] += s2.z; a[7] += s2.w;
   }
+  // inside a wave by shuffles (no barriers: the eight-barrier LDS tree of round 2 was most of this 5 us kernel, which sits 64 times
+  // per step on the dependent chain), then the four waves through LDS -- a fixed order either way
 #pragma unroll
-  for (int k = 0; k < 8; ++k) red[k][r] = a[k];
-  __syncthreads();
-  for (int st = 128; st >= 1; st >>= 1) {
-    if (r < st) {
+  for (int m = 32; m >= 1; m >>= 1) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) red[k][r] += red[k][r + st];
-    }
-    __syncthreads();
+    for (int k = 0; k < 8; ++k) a[k] += __shfl_xor(a[k], m);
   }
+  if ((r & 63) == 0) {
 #pragma unroll
-  for (int k = 0; k < 8; ++k) out[k] = red[k][0];
+    for (int k = 0; k < 8; ++k) red[r >> 6][k] = a[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) out[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
 }
 
 // ---------------------------------------------------------------- BatchNorm statistics finalize

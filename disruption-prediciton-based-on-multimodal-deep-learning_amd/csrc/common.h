@@ -67,6 +67,7 @@ struct PersBwd;     // fused BatchNorm-backward reduction of a data gradient (pa
 int patch_launch(const PatchPlan* p, const float* src, const float* ps, const float* psh, float slope, const float* wp,
                  float* dst, float* stat, int accumulate, hipStream_t s, const PersBwd* bw = nullptr);
 bool patch_can_fuse(const PatchPlan* p);
+int patch_fused_blocks(const PatchPlan* p);     // partial rows written by a fused data gradient (patch_can_fuse)
 
 struct WgradPlan;
 // While one of these is alive on the calling thread, weight-gradient plans are the ones sized to run BESIDE another kernel chain

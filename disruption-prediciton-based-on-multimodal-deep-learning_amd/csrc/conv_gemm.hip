@@ -538,7 +538,7 @@ extern "C" int md_conv_dgrad(const MdConvDesc* d, const float* dy_raw, const flo
 extern "C" int32_t md_conv_dgrad_bnred_blocks(const MdConvDesc* d) {
   if (check_desc(d) != MD_OK) return 0;
   const PatchPlan* pp = patch_lookup(d, 1);
-  return (pp && patch_can_fuse(pp)) ? patch_blocks(pp) : 0;
+  return (pp && patch_can_fuse(pp)) ? patch_fused_blocks(pp) : 0;
 }
 extern "C" int md_conv_dgrad_bnred(const MdConvDesc* d, const float* dy_raw, const float* wpack_dgrad, float* g_out,
                                    int accumulate, const MdActView* y_view, const float* mean, const float* invstd,

@@ -518,7 +518,12 @@ static bool patch_build(const MdConvDesc* d, int dgrad, PGeom* out, size_t* lds_
 #include <atomic>
 static std::atomic<int> g_pers_grid{0};     // > 0: test override of the persistent kernels' grid (md_set_pers_grid)
 extern "C" int md_set_pers_grid(int n) { return g_pers_grid.exchange(n > 0 ? n : 0); }
-struct PersVariant { bool on; PersGeom pg; size_t lds; int grid; };           // persistent-kernel form of the same launch
+struct PersVariant {           // persistent-kernel form of the same launch
+  bool on; PersGeom pg; size_t lds; int grid;
+  // column slices of <= 3 tiles each (data gradient with more than 3 destination tiles): a FUSED launch runs slice by slice, each
+  // with the fused BatchNorm-backward reduction the full-width kernel has no registers for
+  int nsl; PersGeom sl[4]; size_t sl_lds[4];
+};
 struct PatchClass { PGeom g; size_t lds; size_t wp_off; ClassSpec spec; PersVariant pers; };     // wp_off: floats into the packed operand
 struct PatchPlan {
   PGeom g; size_t lds; int N; int dgrad; int ncls; PatchClass cls[8]; PersVariant pers;
@@ -529,7 +534,7 @@ struct PatchPlan {
 // patch, the box is nearly full, and there are at least as many boxes as resident workgroups.  The packed-weight format
 // (K order, N16) does not depend on the box, so both forms read the same operand.
 static void pers_try(const MdConvDesc* d, int dgrad, const ClassSpec* cls, const PGeom& classic, PersVariant* pv) {
-  pv->on = false;
+  pv->on = false; pv->nsl = 0;
   static const int off = getenv("MD_PERS") && atoi(getenv("MD_PERS")) == 0;
   static const int off_f = getenv("MD_PERS_FWD") && atoi(getenv("MD_PERS_FWD")) == 0;
   static const int off_d = getenv("MD_PERS_DGRAD") && atoi(getenv("MD_PERS_DGRAD")) == 0;
@@ -550,6 +555,25 @@ static void pers_try(const MdConvDesc* d, int dgrad, const ClassSpec* cls, const
   if (pg.nit > PERS_MAXI || (pg.nit > 4 && g.N16 > 48) || g.N16 > 96) return;      // instantiated: <= 6 tiles; 8 items only with <= 3 tiles
   pg.m_nbx = magic_of(g.nbx); pg.m_nby = magic_of(g.nby); pg.m_nbt = magic_of(g.nbt);
   pv->on = true; pv->pg = pg; pv->lds = lds; pv->grid = grid;
+  pv->nsl = 0;
+  // (measured slower on the 72-channel data gradients of the 64x64 stage, which are bound by their patch loads and stores, not
+  // by the matrix work a slice saves: 6.07 against 5.97 ms per step, profiles/r03_fuse_fallback.txt; MD_FUSE_SLICES=1 builds them)
+  static const int slices_on = getenv("MD_FUSE_SLICES") && atoi(getenv("MD_FUSE_SLICES")) == 1;
+  if (dgrad && slices_on && g.N16 > 48 && pg.nit <= 4) {
+    int n0 = 0, k = 0; bool ok = true;
+    while (n0 < g.N16 && ok) {
+      const int rem = g.N16 - n0;
+      const int w = (rem >= 80 || rem == 48) ? 48 : (rem > 48 ? 32 : rem);      // 3-tile slices while at least 2 tiles remain behind them
+      if (w < 32 || k >= 4) { ok = false; break; }
+      PersGeom sg = pg; sg.g.N16 = w;
+      size_t sl = 0; int gr = 0;
+      if (!pers_finish(&sg, &sl, &gr)) { ok = false; break; }
+      sg.nboxes = pg.nboxes; sg.nit = pg.nit; sg.m_nbx = pg.m_nbx; sg.m_nby = pg.m_nby; sg.m_nbt = pg.m_nbt;
+      sg.n0 = n0; sg.N16w = g.N16;
+      pv->sl[k] = sg; pv->sl_lds[k] = sl; ++k; n0 += w;
+    }
+    if (ok && n0 == g.N16) pv->nsl = k;
+  }
   if (getenv("MD_PLAN_PRINT")) fprintf(stderr, "  -> persistent: boxes %d grid %d lds %zu nsteps %d nit %d\n", pg.nboxes, grid, lds, pg.nsteps, pg.nit);
 }
 
@@ -762,6 +786,7 @@ int patch_pack(const MdConvDesc* d, int dgrad, const PatchPlan* p, const float* 
 }
 
 // 64-pixel form (HALF): column groups of p->half_npb channels (or narrower when the layer has few boxes)
+static bool pers_can_fuse(const PersVariant& pv);
 static PersBwd no_bwd() { PersBwd n; n.yraw = nullptr; n.scale = n.shift = n.mean = n.invstd = nullptr; n.slope = 1.f; return n; }
 static int patch_launch_half(const PatchPlan* p, const float* src, const float* ps, const float* psh, float slope, const float* wp,
                              float* dst, float* stat, int accumulate, hipStream_t s, const PersBwd* bw) {
@@ -812,9 +837,16 @@ static int patch_launch_one(const PatchPlan* p, const PGeom& g, size_t lds, cons
                             const PersBwd* bw, hipStream_t s) {
   // accumulate: bit 0 = add into dst, bit 16 = src is a pre-split bf16 gradient (data gradient, pack2 excluded)
   if ((accumulate >> 16) & 1) { if (!p->dgrad || g.pack2) return MD_ERR_UNSUPPORTED; }
-  if (pv.on) {
+  if (pv.on && (!bw || pers_can_fuse(pv))) {
     PersBwd none; none.yraw = nullptr; none.scale = none.shift = none.mean = none.invstd = nullptr; none.slope = 1.f;
     return pers_launch(pv.pg, pv.lds, pv.grid, !p->dgrad, src, ps, psh, slope, wp, dst, stat, accumulate, bw ? *bw : none, s);
+  }
+  if (pv.on && bw && pv.nsl > 0) {            // fused, slice by slice (same rows of the partial buffer, disjoint columns)
+    for (int k = 0; k < pv.nsl; ++k) {
+      const int rc = pers_launch(pv.sl[k], pv.sl_lds[k], pv.grid, false, src, ps, psh, slope, wp, dst, stat, accumulate, *bw, s);
+      if (rc != MD_OK) return rc;
+    }
+    return MD_OK;
   }
   if (bw && !p->dgrad) return MD_ERR_UNSUPPORTED;
   if (p->half && &g == &p->g) return patch_launch_half(p, src, ps, psh, slope, wp, dst, stat, accumulate, s, bw);
@@ -872,19 +904,42 @@ static int patch_launch_one(const PatchPlan* p, const PGeom& g, size_t lds, cons
 
 // bw != nullptr: data gradient with the fused BatchNorm-backward reduction (every launch of the plan must have the
 // persistent form: patch_can_fuse); `stat` then receives patch_blocks(p) partial rows.
+// Does the persistent form of this launch carry the fused reduction?  (instantiated without register spills up to 3 channel tiles,
+// and then at most 4 staged items per thread with 3)
+static bool pers_can_fuse(const PersVariant& pv) {
+  static const int maxn = getenv("MD_FUSE_MAXN16") ? atoi(getenv("MD_FUSE_MAXN16")) : 48;      // experiment: larger tile counts spill
+  return pv.on && pv.pg.g.N16 <= maxn && !(pv.pg.g.N16 == 48 && pv.pg.nit > 4) && !(pv.pg.g.N16 > 48 && pv.pg.nit > 4);
+}
+// A FUSED launch of a geometry whose persistent form cannot fuse runs in the per-box form (k_conv_patch: any tile count -- its
+// epilogue walks the tiles one at a time): the 72-channel data gradients of the 64x64 stage then save the separate reduction pass
+// over their 198 MB tensors.  MD_FUSE_PATCH=0: no fused reduction in the per-box kernels at all.
+static bool fuse_per_box(const PersVariant& pv) {
+  static const int patch_off = getenv("MD_FUSE_PATCH") && atoi(getenv("MD_FUSE_PATCH")) == 0;
+  // (measured slower, profiles/r03_fuse_fallback.txt: 6.05 against 5.97 ms per step -- the per-box kernel loses more on these
+  // layers than the saved reduction pass brings -- so the fallback is off unless MD_FUSE_PERS_FALLBACK=1)
+  static const int pers_fallback_on = getenv("MD_FUSE_PERS_FALLBACK") && atoi(getenv("MD_FUSE_PERS_FALLBACK")) == 1;
+  if (patch_off) return false;
+  if (!pv.on) return true;
+  return !pers_can_fuse(pv) && pers_fallback_on;
+}
 bool patch_can_fuse(const PatchPlan* p) {
   if (!p->dgrad) return false;
-  // persistent form: instantiated without register spills up to 3 channel tiles (and then at most 4 staged items per thread with 3);
-  // per-box form (k_conv_patch, round 3): any tile count -- its epilogue walks the tiles one at a time
-  static const int maxn = getenv("MD_FUSE_MAXN16") ? atoi(getenv("MD_FUSE_MAXN16")) : 48;      // experiment: larger tile counts spill
-  static const int patch_off = getenv("MD_FUSE_PATCH") && atoi(getenv("MD_FUSE_PATCH")) == 0;
-  auto ok = [](const PersVariant& pv) {
-    if (!pv.on) return !patch_off;
-    return pv.pg.g.N16 <= maxn && !(pv.pg.g.N16 == 48 && pv.pg.nit > 4) && !(pv.pg.g.N16 > 48 && pv.pg.nit > 4);
-  };
+  auto ok = [](const PersVariant& pv) { return pers_can_fuse(pv) || (pv.on && pv.nsl > 0) || fuse_per_box(pv); };
   if (!p->ncls) return ok(p->pers);
   for (int c = 0; c < p->ncls; ++c) if (!ok(p->cls[c].pers)) return false;
   return true;
+}
+// rows of the partial-sum buffer written by a FUSED launch sequence
+int patch_fused_blocks(const PatchPlan* p) {
+  auto nb = [&](const PGeom& g, const PersVariant& pv) {
+    if (pers_can_fuse(pv) || (pv.on && pv.nsl > 0)) return pers_blocks(pv.pg, pv.grid);
+    if (p->half && &g == &p->g) return p->N * p->gh.nbt * p->gh.nby * p->gh.nbx;
+    return p->N * g.nbt * g.nby * g.nbx;
+  };
+  if (!p->ncls) return nb(p->g, p->pers);
+  int n = 0;
+  for (int c = 0; c < p->ncls; ++c) n += nb(p->cls[c].g, p->cls[c].pers);
+  return n;
 }
 int patch_launch(const PatchPlan* p, const float* src, const float* ps, const float* psh, float slope, const float* wp,
                  float* dst, float* stat, int accumulate, hipStream_t s, const PersBwd* bw) {
@@ -894,7 +949,12 @@ int patch_launch(const PatchPlan* p, const float* src, const float* ps, const fl
     const int rc = patch_launch_one(p, p->cls[c].g, p->cls[c].lds, p->cls[c].pers, src, ps, psh, slope, wp + p->cls[c].wp_off, dst,
                                     stat, accumulate, bw, s);
     if (rc) return rc;
-    if (stat) stat += (size_t)variant_blocks(p, p->cls[c].g, p->cls[c].pers) * 2 * p->cls[c].g.Cpd;
+    if (stat) {
+      const PatchClass& pc = p->cls[c];
+      const int nb = (bw && !pers_can_fuse(pc.pers) && !(pc.pers.on && pc.pers.nsl > 0)) ? p->N * pc.g.nbt * pc.g.nby * pc.g.nbx
+                                                                                        : variant_blocks(p, pc.g, pc.pers);
+      stat += (size_t)nb * 2 * pc.g.Cpd;
+    }
   }
   return MD_OK;
 }

@@ -97,9 +97,10 @@ __global__ __launch_bounds__(512) void k_conv_pers(
   }
   if (FUSE) {
     for (int c = t; c < g.N16; c += NT) {
-      const bool ok = c < g.Cpd;
-      sBn[c] = ok ? bw.scale[c] : 0.f; sBn[bns + c] = ok ? bw.shift[c] : 0.f;
-      sBn[2 * bns + c] = ok ? bw.mean[c] : 0.f; sBn[3 * bns + c] = ok ? bw.invstd[c] : 0.f;
+      const int cg = pg.n0 + c;
+      const bool ok = cg < g.Cpd;
+      sBn[c] = ok ? bw.scale[cg] : 0.f; sBn[bns + c] = ok ? bw.shift[cg] : 0.f;
+      sBn[2 * bns + c] = ok ? bw.mean[cg] : 0.f; sBn[3 * bns + c] = ok ? bw.invstd[cg] : 0.f;
     }
   }
   // resident weights: global [stage][hi|lo][N16][8 chunks] -> LDS [hi|lo][N16][bpitch]
@@ -111,7 +112,8 @@ __global__ __launch_bounds__(512) void k_conv_pers(
       const int hb = rest / g.N16; const int n = rest - hb * g.N16;
       const int h = hb & 1, kb = hb >> 1;
       const int kc = kb * 8 + c;
-      if (kc < kchunks) *(uint4*)(sm + pg.off_bres + (h * g.N16 + n) * pg.bpitch + kc * 16) = wp[idx];
+      // (column slice: row n0 + n of the N16w packed rows; the whole operand when n0 = 0 and N16w = N16)
+      if (kc < kchunks) *(uint4*)(sm + pg.off_bres + (h * g.N16 + n) * pg.bpitch + kc * 16) = wp[((size_t)hb * pg.N16w + pg.n0 + n) * 8 + c];
     }
   }
   __syncthreads();
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(512) void k_conv_pers(
         for (int a = 0; a < 2; ++a) {
           const int pk = rdec[a];
           const bool v = pk >= 0 && (t0 + (pk & 0xff) < g.Td) && (y0 + ((pk >> 8) & 0xff) < g.Hd) && (x0 + ((pk >> 16) & 0xff) < g.Wd);
-          goff[a] = v ? (unsigned)((dbase + drel[a]) * g.Cpd + c0) * 4u : MD_OOB;
+          goff[a] = v ? (unsigned)((dbase + drel[a]) * g.Cpd + pg.n0 + c0) * 4u : MD_OOB;
           gw[a] = v ? 1.f : 0.f;
         }
       }
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(512) void k_conv_pers(
     constexpr int YD = NREP <= 3 ? NREP : 2;
     f32x4 yv[FUSE ? NREP : 1][2];
     auto request_y = [&](int j) __attribute__((always_inline)) {
-      const bool colok = c0 + j * 16 < g.Cpd && cur < pg.nboxes;
+      const bool colok = pg.n0 + c0 + j * 16 < g.Cpd && cur < pg.nboxes;
 #pragma unroll
       for (int a = 0; a < 2; ++a) yv[FUSE ? j : 0][a] = buf_load4_pinned(yrs, colok ? goff[a] + j * 64u : MD_OOB);
     };
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(512) void k_conv_pers(
 #pragma unroll
       for (int j = 0; j < NREP; ++j) {
         if constexpr (FUSE) { if (j + YD < NREP) { request_y(j + YD); __builtin_amdgcn_sched_barrier(0); } }
-        const bool colok = c0 + j * 16 < g.Cpd;
+        const bool colok = pg.n0 + c0 + j * 16 < g.Cpd;
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
           const unsigned off = (colok && !(dbg & 4)) ? goff[a] + j * 64u : MD_OOB;
@@ -405,14 +407,14 @@ __global__ __launch_bounds__(512) void k_conv_pers(
         }
       }
     __syncthreads();
-    if (t < g.N16 && t < g.Cpd) {
+    if (t < g.N16 && pg.n0 + t < g.Cpd) {
       float a1 = 0.f, a2 = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) {
         a1 += red[(w * 2 + 0) * (PNREP * 16) + t];
         a2 += red[(w * 2 + 1) * (PNREP * 16) + t];
       }
-      float* sp = stat_partial + (size_t)blockIdx.x * 2 * g.Cpd;
+      float* sp = stat_partial + (size_t)blockIdx.x * 2 * g.Cpd + pg.n0;
       sp[t] = a1;
       sp[g.Cpd + t] = a2;
     }
@@ -436,6 +438,7 @@ bool pers_finish(PersGeom* pg, size_t* lds_bytes, int* grid) {
   pg->nsteps = md_cdiv(g.Kc8, 4);
   { int u = pg->nsteps * 4; while ((u & 3) != 2) ++u; pg->bpitch = u * 16; }
   pg->nboxes = 0;     // set by the caller (depends on N)
+  pg->n0 = 0; pg->N16w = g.N16;
   pg->patch_bytes = (g.P * g.ppitch + 15) & ~15;
   size_t off = (size_t)2 * pg->patch_bytes;
   pg->off_red = 0;                               // the end-of-kernel reduction scratch aliases the patches

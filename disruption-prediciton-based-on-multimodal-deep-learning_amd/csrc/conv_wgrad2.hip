@@ -432,6 +432,8 @@ const Wgrad2Plan* wgrad2_lookup(const MdConvDesc* d, int beside) {
     int want = md_cdiv(fill * 2, g.nkg * g.nng);
     if (want > g.nboxes) want = g.nboxes;
     if (want < 1) want = 1;
+    // (Fewer, fatter slices for the deep layers -- whose slabs exceed their operands several times over -- measured neutral:
+    // profiles/r03_wgrad2.txt.)
     g.boxes_per_wg = md_cdiv(g.nboxes, want);
     wp = new Wgrad2Plan(); wp->g = g; wp->lds = lds; wp->nslices = md_cdiv(g.nboxes, g.boxes_per_wg);
   }

@@ -146,6 +146,7 @@ struct PersGeom {
   int patch_bytes;          // LDS bytes of one team's patch ([pixel][hi | lo | pad])
   int sc_stride, bn_stride; // floats between the scale | shift (| mean | invstd) rows in LDS
   unsigned m_nbx, m_nby, m_nbt;
+  int n0, N16w;             // column slice: this launch computes destination channels n0 .. n0 + g.N16 of N16w packed weight rows
 };
 // fused BatchNorm-backward reduction (data gradient only); yraw == nullptr: off
 struct PersBwd {

@@ -26,6 +26,7 @@
 #include "patch_common.h"
 #include <cstdlib>
 #include <cstdio>
+#include <type_traits>
 
 // 16-byte buffer store / load at a byte offset (out-of-range offset: dropped / zeros)
 __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned off, f32x4 v) {
@@ -254,11 +255,9 @@ __global__ __launch_bounds__(512) void k_conv_pers(
           gw[a] = v ? 1.f : 0.f;
         }
       }
-      // matrix loop: patch fragments and resident weight fragments from LDS; no barriers
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int j = 0; j < NREP; ++j) acc[a][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // matrix loop: patch fragments and resident weight fragments from LDS; no barriers.  The first K step starts every
+      // accumulator chain from a literal zero C operand instead of 8 * NREP register clears per box (the kernel is bound by
+      // vector-instruction issue: 4 cycles per VALU instruction beside the MFMAs, profiles/r03_pers_issue_model.txt).
       uint4 fa[2][4];
       load_p(sK[lg], fa[0]);
       int ko_next = sK[min(1, pg.nsteps - 1) * 4 + lg];            // tap offset of step q + 1 while step q runs
@@ -270,7 +269,9 @@ __global__ __launch_bounds__(512) void k_conv_pers(
       };
       uint4 w0[2], w1[2];
       load_w(bbase, 0, w0); load_w(bbase, 1 % NREP, w1);
-      auto kstep = [&](const uint4* fcur, uint4* fnext, int q) __attribute__((always_inline)) {
+      auto kstep = [&](auto first_tag, const uint4* fcur, uint4* fnext, int q) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         // patch fragments of the next step (the last step re-reads its own: branch-free), tap offset of the one after
         load_p(ko_next, fnext);
         ko_next = sK[min(q + 2, pg.nsteps - 1) * 4 + lg];
@@ -286,8 +287,8 @@ __global__ __launch_bounds__(512) void k_conv_pers(
           __builtin_amdgcn_sched_barrier(0);            // keep the reads HERE: the scheduler would sink them to their use
           const uint4 wh = wc[0], wl = wc[1];
           // smallest terms first: lo*hi and hi*lo, then hi*hi.  (weights, patch) operand order: D[channel][pixel]
-          acc[0][j] = mma<F16>(wh, pl0, acc[0][j]);
-          acc[1][j] = mma<F16>(wh, pl1, acc[1][j]);
+          acc[0][j] = mma<F16>(wh, pl0, FIRST ? zero : acc[0][j]);
+          acc[1][j] = mma<F16>(wh, pl1, FIRST ? zero : acc[1][j]);
           acc[0][j] = mma<F16>(wl, ph0, acc[0][j]);
           acc[1][j] = mma<F16>(wl, ph1, acc[1][j]);
           acc[0][j] = mma<F16>(wh, ph0, acc[0][j]);
@@ -297,9 +298,19 @@ __global__ __launch_bounds__(512) void k_conv_pers(
         }
         w0[0] = wc[0]; w0[1] = wc[1]; w1[0] = wn[0]; w1[1] = wn[1];
       };
-      int q = (dbg & 2) ? pg.nsteps : 0;
-      for (; q + 1 < pg.nsteps; q += 2) { kstep(fa[0], fa[1], q); kstep(fa[1], fa[0], q + 1); }
-      if (q < pg.nsteps) kstep(fa[0], fa[1], q);
+      if (dbg & 2) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int j = 0; j < NREP; ++j) acc[a][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      } else {
+        typedef std::integral_constant<bool, true> First;
+        typedef std::integral_constant<bool, false> Later;
+        kstep(First(), fa[0], fa[1], 0);
+        int q = 1;
+        for (; q + 1 < pg.nsteps; q += 2) { kstep(Later(), fa[1], fa[0], q); kstep(Later(), fa[0], fa[1], q + 1); }
+        if (q < pg.nsteps) kstep(Later(), fa[1], fa[0], q);
+      }
     }
   };
   auto do_move = [&]() __attribute__((always_inline)) {
@@ -324,6 +335,7 @@ __global__ __launch_bounds__(512) void k_conv_pers(
     // in flight during this epilogue, the hand-over and the whole next matrix phase instead of the matrix phase alone
     if (early_issue && nxt + stride < pg.nboxes) issue(nxt + stride);
     if (cur < pg.nboxes && !(dbg & 32)) {
+      const bool allin = __all(gw[0] != 0.f && gw[1] != 0.f);
 #pragma unroll
       for (int j = 0; j < NREP; ++j) {
         if constexpr (FUSE) { if (j + YD < NREP) { request_y(j + YD); __builtin_amdgcn_sched_barrier(0); } }
@@ -345,8 +357,13 @@ __global__ __launch_bounds__(512) void k_conv_pers(
               s1[j][r] += gm; s2[j][r] = fmaf(gm, (y[r] - mu[r]) * is[r], s2[j][r]);
             }
           } else if (stats) {
+            if (allin) {        // every pixel row of this wave lies inside the tensor (wave-uniform): no row weights
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float vm = v[r] * gw[a]; s1[j][r] += vm; s2[j][r] = fmaf(vm, v[r], s2[j][r]); }
+              for (int r = 0; r < 4; ++r) { s1[j][r] += v[r]; s2[j][r] = fmaf(v[r], v[r], s2[j][r]); }
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { const float vm = v[r] * gw[a]; s1[j][r] += vm; s2[j][r] = fmaf(vm, v[r], s2[j][r]); }
+            }
           }
           buf_store4(drs, off, v);
         }

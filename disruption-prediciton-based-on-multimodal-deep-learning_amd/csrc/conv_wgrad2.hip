@@ -432,8 +432,19 @@ const Wgrad2Plan* wgrad2_lookup(const MdConvDesc* d, int beside) {
     int want = md_cdiv(fill * 2, g.nkg * g.nng);
     if (want > g.nboxes) want = g.nboxes;
     if (want < 1) want = 1;
-    // (Fewer, fatter slices for the deep layers -- whose slabs exceed their operands several times over -- measured neutral:
-    // profiles/r03_wgrad2.txt.)
+    // Every slice writes a full copy of the unit's dW (read back by the reduction): in the deep layers, where a slice would hold one
+    // or two boxes, that traffic exceeds the operands' several times over (64 -> 144 at 16x16: 32 MB of slabs, 10 MB of operands).
+    // There a workgroup takes at least `minb` boxes as long as `minw` workgroups remain: time-neutral (profiles/r03_wgrad2.txt),
+    // 0.4 GB less HBM traffic per step.
+    static const int minb = getenv("MD_W2_MIN_BOXES") ? atoi(getenv("MD_W2_MIN_BOXES")) : 4;
+    static const int minw = getenv("MD_W2_MIN_WGS") ? atoi(getenv("MD_W2_MIN_WGS")) : 128;
+    if (minb > 1 && g.nboxes / want < minb) {
+      int w2 = g.nboxes / minb;
+      const int floor_w = md_cdiv(minw, g.nkg * g.nng);
+      if (w2 < floor_w) w2 = floor_w;
+      if (w2 < 1) w2 = 1;
+      if (w2 < want) want = w2;
+    }
     g.boxes_per_wg = md_cdiv(g.nboxes, want);
     wp = new Wgrad2Plan(); wp->g = g; wp->lds = lds; wp->nslices = md_cdiv(g.nboxes, g.boxes_per_wg);
   }

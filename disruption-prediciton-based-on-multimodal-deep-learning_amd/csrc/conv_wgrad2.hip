@@ -62,13 +62,21 @@ template <int KTW, int NREP> struct W2Items { static constexpr int NX = (KTW * N
 // lo half of an LDS image = its hi half + W2_LO bytes (a compile-time distance: the lo accesses use the instruction offset on
 // the hi address, no second address register)
 #define W2_LO 40960
+// TEAMS: one 8-wave workgroup per CU whose two 4-wave teams are what the two workgroups of the plain form are -- own boxes, own LDS
+// images (team stride W2_TS, lo halves W2_LO_T behind), synchronised only inside a team (LDS counter) -- but they add their
+// accumulators through LDS at the end: ONE slab per CU instead of two (the slabs were 0.8 GB written and read back per step).
+#define W2_TS 24576
+#define W2_LO_T 49152
 
-template <int KTW, int NREP, int NS>
-__global__ __launch_bounds__(256, 2) void k_wgrad2(
+template <int KTW, int NREP, int NS, bool TEAMS = false>
+__global__ __launch_bounds__(TEAMS ? 512 : 256, 2) void k_wgrad2(
     W2Geom g, const float* __restrict__ src, const float* __restrict__ pscale, const float* __restrict__ pshift,
     float pslope, const float* __restrict__ dy, float* __restrict__ slab, int dbg) {
   // dbg (MD_DBG2, timing experiments only): 1 no global loads, 2 no matrix phase, 4 no commit
-  extern __shared__ __attribute__((aligned(16))) char sm[];
+  extern __shared__ __attribute__((aligned(16))) char sm_all[];
+  constexpr int LO = TEAMS ? W2_LO_T : W2_LO;
+  const int team = TEAMS ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;
+  char* sm = sm_all + team * W2_TS;
   char* sP = sm;
   char* sY = sm + g.off_y;
   int* sRx = (int*)(sm + g.off_rows);           // [32 * NS] X patch byte offset of each output row (box independent)
@@ -78,9 +86,26 @@ __global__ __launch_bounds__(256, 2) void k_wgrad2(
   constexpr int NT = 256, PMB = 32 * NS;
   constexpr int NX = W2Items<KTW, NREP>::NX, NY = W2Items<KTW, NREP>::NY;
   constexpr int JH = NREP > 3 ? (NREP + 1) / 2 : NREP;             // column tiles whose B fragments are live together
-  const int t = threadIdx.x;
+  const int t = TEAMS ? ((int)threadIdx.x & 255) : (int)threadIdx.x;      // thread within the team
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  // synchronisation of the four waves that share the images: the workgroup barrier, or a four-wave barrier on an LDS counter
+  int sync_target = 0;                                 // (TEAMS) the teams' counters sit in the last 128 B of the hi regions
+  auto sync = [&]() {
+    if constexpr (!TEAMS) { __syncthreads(); }
+    else {
+      int* c = (int*)(sm_all + W2_LO_T - 128) + team * 16;
+      sync_target += 4;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < sync_target) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+  };
+  if (TEAMS) {
+    if (threadIdx.x < 32) ((int*)(sm_all + W2_LO_T - 128))[threadIdx.x] = 0;
+    __syncthreads();
+  }
   const int li = lane & 15, lg = lane >> 4;
   const int lq = li >> 2, lp = li & 3;
   const int kg = blockIdx.y / g.nng, ng = blockIdx.y - kg * g.nng;
@@ -173,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad2(
   // grid position of the box being requested (wave-uniform, stepped box by box: no divisions in the loop)
   int q_xb, q_yb, q_tb, q_n;
   {
-    int b = blockIdx.x * g.boxes_per_wg;
+    int b = ((TEAMS ? 2 : 1) * blockIdx.x + team) * g.boxes_per_wg;
     q_xb = b % g.nbx; b /= g.nbx;
     q_yb = b % g.nby; b /= g.nby;
     q_tb = b % g.nbt; q_n = b / g.nbt;
@@ -226,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad2(
         split8(v, hi, lo);
         char* d = sP + (xdst[u] & 0xffff);
         *(uint4*)d = hi;
-        *(uint4*)(d + W2_LO) = lo;
+        *(uint4*)(d + LO) = lo;
       }
     }
 #pragma unroll
@@ -237,21 +262,21 @@ __global__ __launch_bounds__(256, 2) void k_wgrad2(
         split8(v, hi, lo);
         char* d = sY + ydst[u];
         *(uint4*)d = hi;
-        *(uint4*)(d + W2_LO) = lo;
+        *(uint4*)(d + LO) = lo;
       }
     }
   };
 
-  const int box_beg = blockIdx.x * g.boxes_per_wg;
+  const int box_beg = min(g.nboxes, ((TEAMS ? 2 : 1) * (int)blockIdx.x + team) * g.boxes_per_wg);
   const int box_end = min(g.nboxes, box_beg + g.boxes_per_wg);
   // experiment (MD_W2_STAGGER = dbg >> 8, units of 512 cycles): delay the second half of the grid -- the workgroups that join an
   // already occupied CU -- so that the two workgroups of a CU do not run their matrix phases in step
-  if ((dbg >> 8) && blockIdx.x >= gridDim.x / 2) for (int i = 0; i < (dbg >> 8); ++i) __builtin_amdgcn_s_sleep(8);
+  if (!TEAMS && (dbg >> 8) && blockIdx.x >= gridDim.x / 2) for (int i = 0; i < (dbg >> 8); ++i) __builtin_amdgcn_s_sleep(8);
   if (box_beg < box_end) issue();
   for (int box = box_beg; box < box_end; ++box) {
-    __syncthreads();          // previous box fully consumed (first iteration: tables / scale in LDS)
+    sync();                   // previous box fully consumed (first iteration: tables / scale in LDS)
     if (!(dbg & 4)) commit();
-    __syncthreads();
+    sync();
     if (box + 1 < box_end) issue();      // in flight during the matrix phase
 #pragma unroll
     for (int s = 0; s < (((dbg & 0xff) & 2) ? 0 : NS); ++s) {
@@ -268,14 +293,14 @@ __global__ __launch_bounds__(256, 2) void k_wgrad2(
         for (int j = 0; j < JH; ++j) {
           if (jb + j < NREP) {
             bh[j] = w2_tr_read2(ya + (jb + j) * 32, yb2 + (jb + j) * 32);
-            bl[j] = w2_tr_read2(ya + W2_LO + (jb + j) * 32, yb2 + W2_LO + (jb + j) * 32);
+            bl[j] = w2_tr_read2(ya + LO + (jb + j) * 32, yb2 + LO + (jb + j) * 32);
           }
         }
 #pragma unroll
         for (int a = 0; a < KTW; ++a) {
           const char* pa = xa + koff[a]; const char* pb = xb2 + koff[a];
           const bf16x8 ah = w2_tr_read2(pa, pb);
-          const bf16x8 al = w2_tr_read2(pa + W2_LO, pb + W2_LO);
+          const bf16x8 al = w2_tr_read2(pa + LO, pb + LO);
 #pragma unroll
           for (int j = 0; j < JH; ++j) {
             if (jb + j < NREP) {
@@ -289,6 +314,27 @@ __global__ __launch_bounds__(256, 2) void k_wgrad2(
     }
   }
 
+  if constexpr (TEAMS) {
+    // team 1 hands its accumulators to team 0 through LDS (the images are dead): [tile][reg][256 threads], conflict-free
+    __syncthreads();
+    float* xch = (float*)sm_all;
+    if (team == 1) {
+#pragma unroll
+      for (int a = 0; a < KTW; ++a)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xch[((a * NREP + j) * 4 + r) * 256 + t] = acc[a][j][r];
+    }
+    __syncthreads();
+    if (team == 1) return;
+#pragma unroll
+    for (int a = 0; a < KTW; ++a)
+#pragma unroll
+      for (int j = 0; j < NREP; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[a][j][r] += xch[((a * NREP + j) * 4 + r) * 256 + t];
+  }
   // ---- slab[slice][(kg * nktg + k-tile) * 16 + row][N16]: D rows = k index (4 * lg + reg), cols = cout (li)
   float* out = slab + (size_t)blockIdx.x * ((size_t)g.nkg * g.nktg * 16 * g.N16);
 #pragma unroll
@@ -344,7 +390,7 @@ __global__ __launch_bounds__(256) void k_wgrad2_reduce(const float* __restrict__
   wgrad2_reduce_body(slab, nslices, rows, KTg, taps, N16, Cout, Cin, dw);
 }
 
-struct Wgrad2Plan { W2Geom g; size_t lds; int nslices; };
+struct Wgrad2Plan { W2Geom g; size_t lds; int nslices; bool teams; size_t lds_teams; };
 
 static bool wgrad2_build(const MdConvDesc* d, W2Geom* out, size_t* lds_bytes) {
   W2Geom g;
@@ -447,6 +493,16 @@ const Wgrad2Plan* wgrad2_lookup(const MdConvDesc* d, int beside) {
     }
     g.boxes_per_wg = md_cdiv(g.nboxes, want);
     wp = new Wgrad2Plan(); wp->g = g; wp->lds = lds; wp->nslices = md_cdiv(g.nboxes, g.boxes_per_wg);
+    // two-team form: the hi halves of both teams' images (and the two counters) within W2_LO_T bytes
+    static const int teams_env = getenv("MD_W2_TEAMS") ? atoi(getenv("MD_W2_TEAMS")) : 1;
+    const size_t hi_part = (size_t)g.off_scale + (size_t)2 * g.C8i * 8 * 4;      // [X hi | dY hi | row table | scale, shift] of one team
+    wp->teams = teams_env && hi_part + 256 <= W2_TS && wp->nslices >= 2;
+    if (wp->teams) {
+      wp->nslices = md_cdiv(wp->nslices, 2);                 // one slab per workgroup = per pair of box ranges
+      const size_t xch = (size_t)g.ktw * g.nrep * 4 * 256 * 4;
+      wp->lds_teams = (size_t)W2_LO_T + W2_TS + hi_part;
+      if (wp->lds_teams < xch) wp->lds_teams = xch;
+    }
   }
   cache[key] = wp;
   return wp;
@@ -458,6 +514,19 @@ template <int KTW, int NREP>
 static int wgrad2_launch_one(const Wgrad2Plan* p, const float* src, const float* ps, const float* psh, float slope, const float* dy,
                              float* slab, hipStream_t s) {
   const W2Geom& g = p->g;
+  if (p->teams) {
+    static bool sett_ = false;
+    if (!sett_) {
+      if (hipFuncSetAttribute((const void*)k_wgrad2<KTW, NREP, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return MD_ERR_LAUNCH;
+      sett_ = true;
+    }
+    static const int dbgt = getenv("MD_DBG2") ? atoi(getenv("MD_DBG2")) : 0;
+    MD_KLAUNCH((k_wgrad2<KTW, NREP, 2, true>), dim3(p->nslices, g.nkg * g.nng), dim3(512), p->lds_teams, s, g, src, ps, psh, slope, dy, slab,
+               dbgt & 0xff);
+    MD_CHECK_LAUNCH();
+    return MD_OK;
+  }
   static bool set_ = false;
   if (!set_) {
     if (hipFuncSetAttribute((const void*)k_wgrad2<KTW, NREP, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)

@@ -81,7 +81,7 @@ int wgrad_patch_launch(const WgradPlan* p, const MdConvDesc* d, const float* src
                        float slope, const float* dy, float* dw, float* slab, hipStream_t s, int ysplit = 0, int xsplit = 0);
 // second form of the weight gradient (conv_wgrad2.hip): two workgroups per CU, 64-pixel boxes, k-groups by input channel
 struct Wgrad2Plan;
-const Wgrad2Plan* wgrad2_lookup(const MdConvDesc* d, int beside);     // nullptr: geometry not handled (first form runs)
+const Wgrad2Plan* wgrad2_lookup(const MdConvDesc* d, int beside, int xpitch = 0, int xc0 = 0, int dw_cin = 0);     // nullptr: not handled (first form runs)
 size_t wgrad2_workspace_floats(const Wgrad2Plan* p);
 int wgrad2_launch(const Wgrad2Plan* p, const MdConvDesc* d, const float* src, const float* ps, const float* psh, float slope,
                   const float* dy, float* dw, float* slab, hipStream_t s);

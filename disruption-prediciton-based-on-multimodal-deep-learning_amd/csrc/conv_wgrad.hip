@@ -724,7 +724,7 @@ const WgradPlan* wgrad_lookup(const MdConvDesc* d, int xpitch, int xc0, int dw_c
     g.boxes_per_wg = md_cdiv(g.nboxes, want);
     ns = md_cdiv(g.nboxes, g.boxes_per_wg);
     wp = new WgradPlan(); wp->g = g; wp->lds = lds; wp->nslices = ns; wp->w8 = w8;
-    wp->v2 = xpitch ? nullptr : wgrad2_lookup(d, beside);
+    wp->v2 = wgrad2_lookup(d, beside, xpitch, xc0, dw_cin);
   }
   cache[key] = wp;
   return wp;

@@ -47,6 +47,8 @@ struct W2Geom {
   unsigned magicC8, magicNC, m_pyx, m_px, m_byx, m_bx;
   int off_y, off_rows, off_scale;
   unsigned x_bytes, y_bytes;
+  int xpitch, xc_base;        // floats per X pixel in memory and first channel read (= Cpi, 0 unless X is a channel slice of a wider tensor)
+  int dw_cin, dw_c0;          // dW's full Cin and the slice's first channel (= Cin, 0 otherwise)
 };
 
 __device__ __forceinline__ bf16x8 w2_tr_read2(const char* p0, const char* p1) {
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(TEAMS ? 512 : 256, 2) void k_wgrad2(
   const bool prologue = pscale != nullptr;
   if (prologue) for (int c = t; c < g.C8i * 8; c += NT) {
     const bool ok = xc0 + c < g.Cpi;            // channel padding: scale = shift = 0 gives leaky(0 * x + 0) = 0
-    sScale[c] = ok ? pscale[xc0 + c] : 0.f; sShift[c] = ok ? pshift[xc0 + c] : 0.f;
+    sScale[c] = ok ? pscale[g.xc_base + xc0 + c] : 0.f; sShift[c] = ok ? pshift[g.xc_base + xc0 + c] : 0.f;
   }
   if (t < PMB) {
     const int rt = mdiv(t, g.m_byx); const int r = t - rt * g.byx;
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(TEAMS ? 512 : 256, 2) void k_wgrad2(
       const int ppt = mdiv(pixel, g.m_pyx); const int r = pixel - ppt * g.pyx;
       const int ppy = mdiv(r, g.m_px); const int ppx = r - ppy * g.px;
       xdst[u] = (pixel * g.ppitch + c8 * 16) | (c8 << 16);
-      xrel[u] = ((ppt * g.Hi + ppy) * g.Wi + ppx) * g.Cpi + xc0 + c8 * 8;
+      xrel[u] = ((ppt * g.Hi + ppy) * g.Wi + ppx) * g.xpitch + g.xc_base + xc0 + c8 * 8;
       xbx[u] = 1u << ppx;
       xbyt[u] = c8 * 2 < xcv4 ? ((1u << ppy) | (1u << (g.py + ppt))) : NEVER;       // (a chunk past the last channel is never loaded: zeros are committed)
     }
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(TEAMS ? 512 : 256, 2) void k_wgrad2(
     const unsigned sx_yt = bits(max(0, -oh), min(g.py - 1, g.Hi - 1 - oh)) | (bits(max(0, -ot), min(g.pt - 1, g.Ti - 1 - ot)) << g.py);
     const unsigned sy_x = bits(0, min(g.bx, g.Wo - x0) - 1);
     const unsigned sy_yt = bits(0, min(g.by, g.Ho - y0) - 1) | (bits(0, min(g.bt, g.To - t0) - 1) << g.by);
-    const int q_xbase = (((q_n * g.Ti + ot) * g.Hi + oh) * g.Wi + ow) * g.Cpi;
+    const int q_xbase = (((q_n * g.Ti + ot) * g.Hi + oh) * g.Wi + ow) * g.xpitch;
     const int q_ybase = (((q_n * g.To + t0) * g.Ho + y0) * g.Wo + x0) * g.Cpo;
     xfl = 0;
 #pragma unroll
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(TEAMS ? 512 : 256, 2) void k_wgrad2(
 // dw[cout][cin][tap] = sum_slices slab[slice][((kg * taps + tap) * KTg + c16) * 16 + cin % 16][cout]   (fixed order)
 // Block = 64 outputs x 4 slice groups: slice group q sums slices q, q+4, ... with four independent chains.
 __device__ __forceinline__ void wgrad2_reduce_body(const float* __restrict__ slab, int nslices, int rows, int KTg, int taps, int N16,
-                                                   int Cout, int Cin, float* __restrict__ dw) {
+                                                   int Cout, int Cin, float* __restrict__ dw, int dw_cin, int dw_c0) {
   __shared__ float red[4][64];
   const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int idx = blockIdx.x * 64 + o;                         // over [rows][N16], cout fastest
@@ -381,18 +383,36 @@ __device__ __forceinline__ void wgrad2_reduce_body(const float* __restrict__ sla
     const int nktg = taps * KTg;
     const int kg = kt / nktg; const int lt = kt - kg * nktg;
     const int tap = lt / KTg; const int c = ((kg * KTg) + (lt - tap * KTg)) * 16 + (krow & 15);
-    if (co < Cout && c < Cin) dw[((size_t)co * Cin + c) * taps + tap] = s;
+    if (co < Cout && c < Cin) dw[((size_t)co * dw_cin + dw_c0 + c) * taps + tap] = s;
   }
 }
 
 __global__ __launch_bounds__(256) void k_wgrad2_reduce(const float* __restrict__ slab, int nslices, int rows, int KTg, int taps, int N16,
-                                                       int Cout, int Cin, float* __restrict__ dw) {
-  wgrad2_reduce_body(slab, nslices, rows, KTg, taps, N16, Cout, Cin, dw);
+                                                       int Cout, int Cin, float* __restrict__ dw, int dw_cin, int dw_c0) {
+  wgrad2_reduce_body(slab, nslices, rows, KTg, taps, N16, Cout, Cin, dw, dw_cin, dw_c0);
 }
 
 struct Wgrad2Plan { W2Geom g; size_t lds; int nslices; bool teams; size_t lds_teams; };
 
-static bool wgrad2_build(const MdConvDesc* d, W2Geom* out, size_t* lds_bytes) {
+static bool wgrad2_build(const MdConvDesc* d_in, W2Geom* out, size_t* lds_bytes, int xpitch = 0, int xc_base = 0, int dw_cin = 0) {
+  // A 1x1x1 unit-stride convolution without padding couples no pixels: its N*T*H*W pixels may be walked as any H' x W' grid.  The
+  // Linears of the transformer models arrive as one row of `rows` pixels (rows laid along W, models/_unit.py::LinearRowsFunction);
+  // they are walked as (rows / w) x w with the divisor w <= 32 that fills the 64-pixel boxes best, so that the box coordinates fit
+  // the validity words (and the boxes are not 1 x 64 strips).
+  MdConvDesc dd = *d_in;
+  if (dd.kt == 1 && dd.kh == 1 && dd.kw == 1 && dd.st == 1 && dd.sh == 1 && dd.sw == 1 && dd.pt == 0 && dd.ph == 0 && dd.pw == 0) {
+    const long long rows = (long long)dd.N * dd.Ti * dd.Hi * dd.Wi;
+    int best_w = 0, best_fill = 0;
+    for (int w = 1; w <= 32; ++w) {
+      if (rows % w) continue;
+      const int by = 64 / w < 1 ? 1 : 64 / w;
+      const long long h = rows / w;
+      const int fill = (int)((h < by ? h : by) * w);
+      if (fill >= best_fill) { best_fill = fill; best_w = w; }
+    }
+    if (best_w && rows / best_w < (1ll << 24)) { dd.N = 1; dd.Ti = dd.To = 1; dd.Hi = dd.Ho = (int)(rows / best_w); dd.Wi = dd.Wo = best_w; }
+  }
+  const MdConvDesc* d = &dd;
   W2Geom g;
   g.st = d->st; g.sh = d->sh; g.sw = d->sw;
   g.Ti = d->Ti; g.Hi = d->Hi; g.Wi = d->Wi; g.Cpi = md_cpad(d->Cin);
@@ -415,7 +435,9 @@ static bool wgrad2_build(const MdConvDesc* d, W2Geom* out, size_t* lds_bytes) {
   g.pmb = 64;
   g.magicC8 = magic_of(g.C8i); g.magicNC = magic_of(g.NC);
   {
-    const unsigned long long xb = (unsigned long long)d->N * g.Ti * g.Hi * g.Wi * g.Cpi * 4ull;
+    g.xpitch = xpitch ? xpitch : g.Cpi; g.xc_base = xpitch ? xc_base : 0;
+    g.dw_cin = xpitch ? dw_cin : d->Cin; g.dw_c0 = xpitch ? xc_base : 0;
+    const unsigned long long xb = (unsigned long long)d->N * g.Ti * g.Hi * g.Wi * g.xpitch * 4ull;
     const unsigned long long yb = (unsigned long long)d->N * g.To * g.Ho * g.Wo * g.Cpo * 4ull;
     if (xb >= 0x80000000ull || yb >= 0x80000000ull) return false;      // buffer addressing: 2 GiB per tensor
     g.x_bytes = (unsigned)xb; g.y_bytes = (unsigned)yb;
@@ -457,19 +479,19 @@ static bool wgrad2_build(const MdConvDesc* d, W2Geom* out, size_t* lds_bytes) {
   return true;
 }
 
-const Wgrad2Plan* wgrad2_lookup(const MdConvDesc* d, int beside) {
+const Wgrad2Plan* wgrad2_lookup(const MdConvDesc* d, int beside, int xpitch, int xc0, int dw_cin) {
   static const int dis = getenv("MD_WGRAD2") && atoi(getenv("MD_WGRAD2")) == 0;
   if (dis) return nullptr;
   static std::mutex mu;
-  static std::map<std::array<int, 19>, Wgrad2Plan*> cache;
-  std::array<int, 19> key = {d->N, d->Ti, d->Hi, d->Wi, d->Cin, d->To, d->Ho, d->Wo, d->Cout, d->kt, d->kh, d->kw,
-                             d->st, d->sh, d->sw, d->pt, d->ph, d->pw, beside ? 1 : 0};
+  static std::map<std::array<int, 22>, Wgrad2Plan*> cache;
+  std::array<int, 22> key = {d->N, d->Ti, d->Hi, d->Wi, d->Cin, d->To, d->Ho, d->Wo, d->Cout, d->kt, d->kh, d->kw,
+                             d->st, d->sh, d->sw, d->pt, d->ph, d->pw, beside ? 1 : 0, xpitch, xc0, dw_cin};
   std::lock_guard<std::mutex> lock(mu);
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
   Wgrad2Plan* wp = nullptr;
   W2Geom g; size_t lds = 0;
-  if (wgrad2_build(d, &g, &lds)) {
+  if (wgrad2_build(d, &g, &lds, xpitch, xc0, dw_cin)) {
     // one slab of partial sums per workgroup: two resident workgroups per CU, the whole chip whatever the executor's schedule
     // (the plan, and with it the summation order, does not depend on the schedule: both give the same bits)
     static const int fill_env = getenv("MD_WGRAD_FILL") ? atoi(getenv("MD_WGRAD_FILL")) : 0;
@@ -569,19 +591,19 @@ int wgrad2_launch(const Wgrad2Plan* p, const MdConvDesc* d, const float* src, co
   if (rc != MD_OK) return rc;
   const int rows = g.nkg * g.nktg * 16;
   MD_KLAUNCH(k_wgrad2_reduce, dim3(md_cdiv(rows * g.N16, 64)), dim3(256), 0, s, slab, p->nslices, rows, g.KTg, g.taps, g.N16, d->Cout,
-             d->Cin, dw);
+             d->Cin, dw, g.dw_cin, g.dw_c0);
   MD_CHECK_LAUNCH();
   return MD_OK;
 }
 
 // ---- the slab reductions of several weight gradients in one launch (blockIdx.y = which one); same sums, same order
 #define W2_RB_MAX 40
-struct W2RedItem { const float* slab; float* dw; int nslices, rows, KTg, taps, N16, Cout, Cin, pad; };
+struct W2RedItem { const float* slab; float* dw; int nslices, rows, KTg, taps, N16, Cout, Cin, dw_cin, dw_c0, pad; };
 struct W2RedBatch { W2RedItem it[W2_RB_MAX]; };
 __global__ __launch_bounds__(256) void k_wgrad2_reduce_batch(W2RedBatch b) {
   const W2RedItem& q = b.it[blockIdx.y];
   if ((int)blockIdx.x * 64 >= q.rows * q.N16) return;
-  wgrad2_reduce_body(q.slab, q.nslices, q.rows, q.KTg, q.taps, q.N16, q.Cout, q.Cin, q.dw);
+  wgrad2_reduce_body(q.slab, q.nslices, q.rows, q.KTg, q.taps, q.N16, q.Cout, q.Cin, q.dw, q.dw_cin, q.dw_c0);
 }
 int wgrad2_reduce_batch(int n, const WgradPending* items, hipStream_t s) {
   for (int base = 0; base < n; base += W2_RB_MAX) {
@@ -590,7 +612,7 @@ int wgrad2_reduce_batch(int n, const WgradPending* items, hipStream_t s) {
       const W2Geom& g = items[i].p->g;
       W2RedItem& q = b.it[cnt];
       q.slab = items[i].slab; q.dw = items[i].dw; q.nslices = items[i].p->nslices; q.rows = g.nkg * g.nktg * 16; q.KTg = g.KTg;
-      q.taps = g.taps; q.N16 = g.N16; q.Cout = items[i].Cout; q.Cin = items[i].Cin; q.pad = 0;
+      q.taps = g.taps; q.N16 = g.N16; q.Cout = items[i].Cout; q.Cin = items[i].Cin; q.dw_cin = g.dw_cin; q.dw_c0 = g.dw_c0; q.pad = 0;
       const int nb = md_cdiv(q.rows * q.N16, 64);
       if (nb > maxb) maxb = nb;
     }

@@ -42,7 +42,7 @@ PEAK_16BIT_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16/fp16 MF
 PRODUCTS_PER_MULTIPLY = 3              # split arithmetic: hi*hi + hi*lo + lo*hi
 PEAK_SPLIT_TFLOPS = PEAK_16BIT_MFMA_TFLOPS / PRODUCTS_PER_MULTIPLY
 PEAK_HBM_GBS = 8000.0
-EVENT_EVERY = 5                         # timed steps between two steps whose conv launches are bracketed with HIP events
+EVENT_EVERY = 10                        # timed steps between two steps whose conv launches are timed with HIP events
 
 
 def synth_batch(device, seed):
@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="experiment: no HIP events around the conv launches (roofline fields become meaningless)")
     ap.add_argument("--torch-optimizer", action="store_true", help="torch clip_grad_norm_ + fused AdamW instead of src.optim.ClipAdamW")
+    ap.add_argument("--composed-step", action="store_true", help="the step as model() / loss / backward() / optimizer.step() from Python instead of the one-call md_plan_train_step (src/_step.py; same kernels, bit-identical)")
     args = ap.parse_args()
 
     # The GPU box exposes every hardware thread of the host but grants one GPU's share of CPU time (cgroup quota: 16 CPUs).  A torch
@@ -169,6 +170,12 @@ def main():
         opt = ClipAdamW(model.parameters(), lr=2e-4)      # same arithmetic as clip_grad_norm_ + AdamW, three launches
     x, y = synth_batch(device, 1234 + rank)
     finite = torch.ones((), device=device)
+    # N = 1: the step the training loop itself takes for this (model, loss, optimizer) triple (src/train.py::train_per_epoch ->
+    # src/_step.py::FusedTrainStep -> md_plan_train_step): forward, Focal loss, backward, clip and AdamW queued by ONE C call
+    fused = None
+    if reducer is None and not args.torch_optimizer and not args.composed_step and os.environ.get("MD_FUSED_STEP", "1") != "0":
+        from src._step import FusedTrainStep
+        fused = FusedTrainStep(model, loss_fn, opt)
 
     def step():
         nonlocal finite
@@ -177,6 +184,10 @@ def main():
             # gradients during backward, one bucket for the rest + the collective finite flag, device-side skip; no host sync)
             loss, _, ok = dp_train_step(model, reducer, opt, loss_fn, x, y, max_norm_grad=1.0)
             finite = finite * ok.reshape(())
+            return
+        if fused is not None:
+            _, _, _, ok = fused(x, y, max_norm=1.0)
+            finite = finite * ok                                      # the device flag of the finite-loss guard: read after the timed region
             return
         opt.zero_grad(set_to_none=True)
         logits = model(x)
@@ -200,10 +211,15 @@ def main():
         rccl_messages = list(reducer.messages)
         reducer.log_messages = False
     plan = model.res2plus1d._plans[(B_PER_GPU, T, S, S)]
-    # Kernel durations for the roofline object come from HIP events around every conv launch.  Bracketing every launch of
-    # every step costs ~8 % of the step (measured: 1137 vs 1231 clips/s), so the timed region samples every
-    # EVENT_EVERY-th step (step 0, 5, 10, ...): the events are live and inside the timed region, the perturbation ~1.5 %.
+    # Kernel durations for the roofline object come from HIP events stamped by the conv launches themselves (hipExtLaunchKernel's
+    # start / stop events, csrc/common.h::md_klaunch).  A timed launch does not overlap its neighbours' dispatch, which costs a sampled
+    # step ~0.45 ms (6.23 vs 5.76 ms), so the timed region samples every EVENT_EVERY-th step (step 0, 10, ...): the events are live
+    # and inside the timed region, the perturbation < 1 %.
     plan.profile_enable(True); plan.profile_enable(False)        # forget anything recorded during warm-up
+    if not args.no_kernel_events:
+        # the event pairs of every sampled step exist before the clock starts (created on first use they cost the host 11-13 ms per
+        # sampled step: 380 hipEventCreate calls, long enough for the GPU queue to run dry)
+        plan.profile_reserve(((args.steps + EVENT_EVERY - 1) // EVENT_EVERY) * 3 * plan.num_units + 64)
     sampled = [0]
 
     def events_for(i):
@@ -309,6 +325,8 @@ def main():
                            "alg_hbm_gbs_fp32": round(step_gbs, 1),
                            "hbm_frac_of_8TBs": round(step_gbs / PEAK_HBM_GBS, 4)},
             "step_trace": step_trace,
+            "step_issue": ("one C call per step (md_plan_train_step via src/_step.py::FusedTrainStep)" if fused is not None else
+                           "composed from Python (model() / loss / backward() / optimizer.step())"),
         }
         if rccl_messages is not None:
             out["rccl_messages_per_step"] = {"count": len(rccl_messages), "bytes": int(sum(b for _, b in rccl_messages)),

@@ -1,7 +1,11 @@
 // Shared declarations for the gfx950 kernels of the disruption-predictor hot path.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
+#include <tuple>
+#include <type_traits>
+#include <utility>
 #include "../../include/mi355x_disrupt.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -12,12 +16,36 @@ static inline int md_cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t md_cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int md_round_up(int a, int b) { return md_cdiv(a, b) * b; }
 
+// Measurement hook (plan.hip::ProfScope, the roofline leg of bench.py): while a scope is open on this thread every launch asks it for a
+// (start, stop) event pair and goes through hipExtLaunchKernel, which stamps the two events from the dispatch packet's own completion
+// signal.  Bracketing launches with hipEventRecord instead cost the host ~35 us per record (13 ms per sampled step, the GPU queue ran
+// dry) and put two barrier packets around every kernel.
+struct MdProfHook { void* ctx; int (*acquire)(void* ctx, hipEvent_t* start, hipEvent_t* stop); };
+extern thread_local MdProfHook g_md_prof_hook;
+
+template <typename... P, size_t... I>
+static inline void md_klaunch_fill(std::tuple<P...>& vals, void** ptrs, std::index_sequence<I...>) {
+  ((ptrs[I] = (void*)&std::get<I>(vals)), ...);
+}
+template <typename... P, typename... A>
+static inline void md_klaunch(void (*kernel)(P...), dim3 g, dim3 b, size_t sh, hipStream_t s, A&&... args) {
+  static_assert(sizeof...(P) == sizeof...(A), "kernel argument count");
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (g_md_prof_hook.ctx && g_md_prof_hook.acquire(g_md_prof_hook.ctx, &e0, &e1)) {
+    std::tuple<std::remove_cv_t<P>...> vals{static_cast<P>(args)...};
+    void* ptrs[sizeof...(P) + 1];
+    md_klaunch_fill(vals, ptrs, std::index_sequence_for<P...>{});
+    (void)hipExtLaunchKernel((const void*)kernel, g, b, ptrs, sh, s, e0, e1, 0);
+  } else {
+    kernel<<<g, b, sh, s>>>(static_cast<P>(args)...);
+  }
+}
 // hipGetLastError() reports the last error of ANY earlier HIP call on this thread (e.g. a benign failure inside the
 // host framework's start-up), so the sticky state is cleared right before every launch and read right after it.
 #define MD_KLAUNCH(...)              \
   do {                               \
     (void)hipGetLastError();         \
-    hipLaunchKernelGGL(__VA_ARGS__); \
+    md_klaunch(__VA_ARGS__);         \
   } while (0)
 
 #define MD_CHECK_LAUNCH()                                  \

@@ -44,9 +44,11 @@ struct Prof {
   bool on = false;
   std::vector<hipEvent_t> pool;   // pairs (start, stop)
   std::vector<int> cls;           // class of pair i
-  std::vector<double> flop;       // algorithmic FLOPs of pair i
+  std::vector<double> flop;       // algorithmic FLOPs of pair i (on the first launch of an operation)
+  std::vector<unsigned char> first;   // pair i is the first launch of its operation (the launch count is per operation)
   size_t used = 0;                // pairs recorded since the last read
 };
+thread_local MdProfHook g_md_prof_hook = {nullptr, nullptr};
 
 struct MdPlan {
   Prof prof;
@@ -298,22 +300,29 @@ extern "C" int32_t md_plan_feat_dim(const MdPlan* p) { return p ? p->feat_dim : 
 static double unit_flops(const Unit& u) {
   return 2.0 * (double)u.rows * u.d.Cout * u.d.Cin * u.d.kt * u.d.kh * u.d.kw;
 }
-// bracket one launch with events; a no-op unless profiling is enabled
+// time the launches of one convolution operation; a no-op unless profiling is enabled.  Every launch made while the scope is open gets
+// its own event pair, stamped by the dispatch itself (common.h::md_klaunch)
 struct ProfScope {
-  MdPlan* P; hipStream_t s; size_t idx; bool on;
-  ProfScope(MdPlan* P_, int cls, double flop, void* stream) : P(P_), s((hipStream_t)stream), idx(0), on(P_->prof.on) {
-    if (!on) return;
-    Prof& pr = P->prof;
+  MdPlan* P; int cls; double flop; bool on; bool any;
+  static int acquire(void* ctx, hipEvent_t* a, hipEvent_t* b) {
+    ProfScope* sc = (ProfScope*)ctx;
+    Prof& pr = sc->P->prof;
     if (pr.used * 2 + 2 > pr.pool.size()) {
-      hipEvent_t a, b;
-      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
-      pr.pool.push_back(a); pr.pool.push_back(b); pr.cls.push_back(0); pr.flop.push_back(0.0);
+      hipEvent_t x, y;
+      if (hipEventCreate(&x) != hipSuccess) return 0;
+      if (hipEventCreate(&y) != hipSuccess) { (void)hipEventDestroy(x); return 0; }
+      pr.pool.push_back(x); pr.pool.push_back(y); pr.cls.push_back(0); pr.flop.push_back(0.0); pr.first.push_back(0);
     }
-    idx = pr.used++;
-    pr.cls[idx] = cls; pr.flop[idx] = flop;
-    (void)hipEventRecord(pr.pool[2 * idx], s);
+    const size_t idx = pr.used++;
+    pr.cls[idx] = sc->cls; pr.flop[idx] = sc->any ? 0.0 : sc->flop; pr.first[idx] = sc->any ? 0 : 1;
+    sc->any = true;
+    *a = pr.pool[2 * idx]; *b = pr.pool[2 * idx + 1];
+    return 1;
   }
-  ~ProfScope() { if (on) (void)hipEventRecord(P->prof.pool[2 * idx + 1], s); }
+  ProfScope(MdPlan* P_, int cls_, double flop_, void*) : P(P_), cls(cls_), flop(flop_), on(P_->prof.on), any(false) {
+    if (on) { g_md_prof_hook.ctx = this; g_md_prof_hook.acquire = &ProfScope::acquire; }
+  }
+  ~ProfScope() { if (on) { g_md_prof_hook.ctx = nullptr; g_md_prof_hook.acquire = nullptr; } }
 };
 
 // 0: queue the weight gradients on the caller's stream (serial schedule), 1: use the side stream (default when the
@@ -350,6 +359,18 @@ extern "C" int md_plan_profile_enable(MdPlan* P, int enable) {
   if (enable == 1) P->prof.used = 0;        // 0 (off) and 2 (resume) keep what has been recorded: sampling some steps of a run
   return MD_OK;
 }
+// Create the event pairs for `records` timed launches ahead of time (hipEventCreate is not free; keep it out of timed regions).
+extern "C" int md_plan_profile_reserve(MdPlan* P, int32_t records) {
+  if (!P) return MD_ERR_NULL;
+  Prof& pr = P->prof;
+  while (pr.pool.size() < (size_t)2 * (size_t)(records > 0 ? records : 0)) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess) return MD_ERR_LAUNCH;
+    if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return MD_ERR_LAUNCH; }
+    pr.pool.push_back(a); pr.pool.push_back(b); pr.cls.push_back(0); pr.flop.push_back(0.0); pr.first.push_back(0);
+  }
+  return MD_OK;
+}
 // Sum of event-measured durations (ms), launch counts and algorithmic FLOPs per class since the last read
 // (classes: 0 conv forward, 1 conv data-gradient, 2 conv weight-gradient).  Synchronises on the recorded events.
 extern "C" int md_plan_profile_read(MdPlan* P, double* ms, int64_t* launches, double* flops) {
@@ -360,7 +381,7 @@ extern "C" int md_plan_profile_read(MdPlan* P, double* ms, int64_t* launches, do
     if (hipEventSynchronize(pr.pool[2 * i + 1]) != hipSuccess) return MD_ERR_LAUNCH;
     float t = 0.f;
     if (hipEventElapsedTime(&t, pr.pool[2 * i], pr.pool[2 * i + 1]) != hipSuccess) return MD_ERR_LAUNCH;
-    ms[pr.cls[i]] += t; launches[pr.cls[i]] += 1; flops[pr.cls[i]] += pr.flop[i];
+    ms[pr.cls[i]] += t; launches[pr.cls[i]] += pr.first[i] ? 1 : 0; flops[pr.cls[i]] += pr.flop[i];
   }
   pr.used = 0;
   return MD_OK;

@@ -30,6 +30,21 @@ class MdActView(C.Structure):
     _fields_ = [("data", c_void_p), ("scale", c_void_p), ("shift", c_void_p), ("slope", C.c_float)]
 
 
+class MdTrainStepArgs(C.Structure):
+    """include/mi355x_disrupt.h::MdTrainStepArgs, field for field."""
+    _fields_ = ([(n, C.c_int32) for n in ("B", "Hd", "K", "loss_kind")] +
+                [(n, c_void_p) for n in ("x", "target", "w", "gamma", "beta", "rmean", "rvar", "dw", "dgamma", "dbeta",
+                                         "w0", "b0", "hgamma", "hbeta", "w1", "b1", "hrmean", "hrvar",
+                                         "dw0", "db0", "dhgamma", "dhbeta", "dw1", "db1")] +
+                [(n, C.c_float) for n in ("head_alpha", "head_eps", "head_momentum", "gamma_or_s")] +
+                [(n, c_void_p) for n in ("class_weight", "margins", "feat", "dfeat", "logits", "dlogits", "head_save", "loss", "pred",
+                                         "workspace", "counters")] +
+                [("ncounters", C.c_int32), ("opt_nchunks", C.c_int32)] +
+                [(n, c_void_p) for n in ("opt_tensors", "opt_chunks", "opt_partial")] +
+                [(n, C.c_float) for n in ("max_norm", "lr", "beta1", "beta2", "eps", "weight_decay")] +
+                [("opt_step", C.c_int64), ("ok_flag", c_void_p)])
+
+
 # name -> (restype, argtypes); mirrors include/mi355x_disrupt.h one to one
 _P = c_void_p
 _I32, _I64, _F, _SZ = C.c_int32, C.c_int64, C.c_float, C.c_size_t
@@ -91,7 +106,9 @@ SIGNATURES = {
     "md_plan_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "md_plan_backward_range": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P]),
     "md_plan_feat_dim": (_I32, [_P]),
+    "md_plan_train_step": (C.c_int, [_P, C.POINTER(MdTrainStepArgs), _P]),
     "md_plan_profile_enable": (C.c_int, [_P, C.c_int]),
+    "md_plan_profile_reserve": (C.c_int, [_P, _I32]),
     "md_plan_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "md_plan_use_side_stream": (C.c_int, [_P, _I32]),
     "md_plan_defer_join": (C.c_int, [_P, _I32]),

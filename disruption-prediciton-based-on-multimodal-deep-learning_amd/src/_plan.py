@@ -49,7 +49,7 @@ class TrunkPlan:
             pass
 
     def use_side_stream(self, on: bool) -> None:
-        """Backward schedule (md_plan_use_side_stream): concurrent weight gradients (default) or one serial stream."""
+        """Backward schedule (md_plan_use_side_stream): weight gradients on a side stream, or everything on one stream (default)."""
         N.check(N.lib().md_plan_use_side_stream(self._h, int(bool(on))), "md_plan_use_side_stream")
 
     def side_stream(self):
@@ -66,6 +66,10 @@ class TrunkPlan:
     def profile_enable(self, on, keep: bool = False) -> None:
         """HIP events around every conv launch; keep=True resumes without forgetting earlier records (step sampling)."""
         N.check(N.lib().md_plan_profile_enable(self._h, (2 if keep else 1) if on else 0), "md_plan_profile_enable")
+
+    def profile_reserve(self, records: int) -> None:
+        """Create the event pairs for that many bracketed launches ahead of a timed region."""
+        N.check(N.lib().md_plan_profile_reserve(self._h, int(records)), "md_plan_profile_reserve")
 
     def profile_read(self):
         """[(ms, launches, flops)] for conv forward / data-gradient / weight-gradient since the last read."""

@@ -101,6 +101,24 @@ def _graphed_step(model, loss_fn, inputs, tgt, model_type):
     return gs
 
 
+# One C call per training step where the (model, loss, optimizer) triple allows it (src/_step.py: R2Plus1DClassifier + Focal / LDAM /
+# CE + ClipAdamW); MD_FUSED_STEP=0 keeps the composed step.
+_FUSED_STEPS = os.environ.get("MD_FUSED_STEP", "1") != "0"
+
+
+def _fused_step(model, loss_fn, optimizer):
+    from . import _step
+    if not _step.applicable(model, loss_fn, optimizer):        # looked at once per epoch (hooks, parameter groups ... can change)
+        return None
+    key = (id(loss_fn), id(optimizer))
+    slot = model.__dict__.get("_md_fused")
+    if slot is not None and slot[0] == key:
+        return slot[1]
+    fs = _step.FusedTrainStep(model, loss_fn, optimizer)
+    model.__dict__["_md_fused"] = (key, fs)
+    return fs
+
+
 def _pred_of(loss_fn, output):
     """argmax softmax(output) (src/train.py:70).  The fused loss kernel already produced it for `output`."""
     p = getattr(loss_fn, "last_pred", None)
@@ -130,11 +148,28 @@ def train_per_epoch(
     total_size = 0
 
     graph_ok = _GRAPH_STEPS and torch.device(device).type == "cuda" and isinstance(loss_fn, torch.nn.Module)
+    fused = None
+    if _FUSED_STEPS and not graph_ok and model_type == "single" and torch.device(device).type == "cuda":
+        fused = _fused_step(model, loss_fn, optimizer)
+    fused_ok = []                # (index into total_pred, batch_idx, device flag) of the fused steps: read once, after the loop
     full_shape = None            # graph mode: the shape of the first batch is the one that is captured
     was_eager = True
     for batch_idx, (data, target) in enumerate(train_loader):
         tgt = target.to(device)
         gs = None
+        if fused is not None:
+            # forward + loss + backward + clip + update in one call; a non-finite loss leaves the parameters alone (device flag)
+            loss, output, pred, ok = fused(data.to(device), tgt, max_norm=max_norm_grad)
+            okb = ok > 0
+            ld = torch.where(okb, loss, torch.zeros_like(loss))
+            loss_sum = ld if loss_sum is None else loss_sum + ld
+            c = (pred.eq(tgt.view_as(pred)) & okb).sum()
+            correct = c if correct is None else correct + c
+            fused_ok.append((len(total_pred), batch_idx, ok))
+            total_pred.append(pred.view(-1, 1))
+            total_label.append(tgt.view(-1, 1))
+            total_size += pred.size(0)
+            continue
         if graph_ok:
             inputs = [data.to(device)] if model_type == "single" else [data['video'].to(device), data['0D'].to(device)]
             shape = tuple(tuple(t.shape) for t in inputs)
@@ -182,6 +217,17 @@ def train_per_epoch(
         total_size += pred.size(0)
         total_pred.append(pred.view(-1, 1))
         total_label.append(tgt.view(-1, 1))
+
+    if fused_ok:
+        flags = torch.stack([f for _, _, f in fused_ok]).cpu().tolist()     # the epoch's one read of the finite-loss flags
+        drop = set()
+        for (slot, bidx, _), f in zip(fused_ok, flags):
+            if f != 1.0:
+                print("train_per_epoch | Warning : loss nan occurs at batch_idx : {}".format(bidx))
+                drop.add(slot)
+        total_pred = [t for i, t in enumerate(total_pred) if i not in drop]
+        total_label = [t for i, t in enumerate(total_label) if i not in drop]
+        total_size = sum(t.size(0) for t in total_pred)
 
     if scheduler:
         scheduler.step()

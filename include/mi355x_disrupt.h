@@ -457,7 +457,9 @@ int32_t md_plan_feat_dim(const MdPlan* p);
 /* Backward schedule: with enable != 0 (default) the weight gradient of a unit is queued on an internal
  * stream as soon as the unit's output gradient is final, concurrently with the BatchNorm-backward / data-gradient chain
  * on the caller's stream; every md_plan_backward_range call joins the two before returning to the caller's stream
- * order.  enable == 0 queues everything on the caller's stream.  Same kernels, bit-identical results. */
+ * order.  enable == 0 queues everything on the caller's stream.  Same kernels, bit-identical results.  Since round 3 the
+ * default is ONE stream (the weight-gradient kernels fill the chip by themselves: profiles/r03_schedule_sweep.txt); the side
+ * stream is created on request (enable != 0 here, or MD_WGRAD_STREAM=1). */
 int md_plan_use_side_stream(MdPlan* p, int32_t enable);
 /* Data-parallel use: md_plan_defer_join(p, 1) makes md_plan_backward_range return WITHOUT ordering the caller's stream
  * after the side stream.  The caller then queues the consumer of a stage's weight gradients (the all-reduce) behind
@@ -474,7 +476,49 @@ int md_plan_join(MdPlan* p, void* stream);
  * enable: 0 = off (records are kept), 1 = on and forget earlier records, 2 = on, keeping earlier records (to sample
  * some steps of a run: the events cost ~8 % of a step when every launch of every step is bracketed). */
 int md_plan_profile_enable(MdPlan* p, int enable);
+/* Create the events for `records` bracketed launches now (outside a timed region) instead of on first use. */
+int md_plan_profile_reserve(MdPlan* p, int32_t records);
 int md_plan_profile_read(MdPlan* p, double* ms, int64_t* launches, double* flops);
+
+/* ------------------------------------------------------------------------------------------------
+ * One training step of R2Plus1DClassifier in ONE call: replaces, for this model, the per-step sequence of the reference's
+ * loop (src/train.py:40-66: optimizer.zero_grad -> model(data) -> loss_fn -> isfinite check -> loss.backward ->
+ * clip_grad_norm_ -> optimizer.step) and the module forward it drives (src/models/R2Plus1D.py:262-265: trunk, then the
+ * Linear -> BatchNorm1d -> ELU -> Linear head).  Everything is queued on `stream`; nothing is read back.
+ * The reference's "skip the batch when the loss is not finite" (train.py:56-58) is a device flag here: ok_flag[0] = 1.0 when
+ * the loss is finite, else 0.0, and the parameter update is applied only when it is 1 (the host looks at the flag later --
+ * per epoch -- for the warning and the bookkeeping).  Gradients are WRITTEN (not accumulated) into dw / dgamma / dbeta / the
+ * head gradient buffers, which the caller exposes as the parameters' .grad.
+ * Tables w, gamma, beta, rmean, rvar, dw, dgamma, dbeta: host arrays of md_plan_num_units() device pointers, as for
+ * md_plan_forward / md_plan_backward.  counters: DEVICE array of ncounters device pointers to int64 scalars
+ * (BatchNorm num_batches_tracked), each incremented by one; may be NULL.  Optimizer: the tensor / chunk tables of
+ * md_opt_grad_norm / md_opt_adamw_step_if over every parameter that is updated (opt_nchunks = 0: no update at all),
+ * opt_partial = opt_nchunks + 2 floats ([0] receives the gradient norm, [1] the clip coefficient), max_norm <= 0: no
+ * clipping; opt_step = the 1-based step count of the bias correction.
+ * loss_kind / class_weight / margins / gamma_or_s as md_softmax_loss.  feat, dfeat: B x md_plan_feat_dim floats; logits,
+ * dlogits: B x K; head_save: md_head_save_floats(B, D, Hd); loss: 1 float; pred: B int64 (argmax softmax, train.py:70). */
+typedef struct MdTrainStepArgs {
+  int32_t B, Hd, K, loss_kind;
+  const float* x;              /* (B,3,T,H,W) fp32 */
+  const int64_t* target;       /* B */
+  const float* const* w; const float* const* gamma; const float* const* beta;
+  float* const* rmean; float* const* rvar;
+  float* const* dw; float* const* dgamma; float* const* dbeta;
+  const float* w0; const float* b0; const float* hgamma; const float* hbeta; const float* w1; const float* b1;
+  float* hrmean; float* hrvar;
+  float* dw0; float* db0; float* dhgamma; float* dhbeta; float* dw1; float* db1;
+  float head_alpha, head_eps, head_momentum, gamma_or_s;
+  const float* class_weight; const float* margins;
+  float* feat; float* dfeat; float* logits; float* dlogits; float* head_save; float* loss; int64_t* pred;
+  void* workspace;             /* md_plan_workspace_bytes */
+  int64_t* const* counters; int32_t ncounters;
+  int32_t opt_nchunks;
+  const void* opt_tensors; const void* opt_chunks; float* opt_partial;
+  float max_norm, lr, beta1, beta2, eps, weight_decay;
+  int64_t opt_step;
+  float* ok_flag;
+} MdTrainStepArgs;
+int md_plan_train_step(MdPlan* plan, const MdTrainStepArgs* args, void* stream);
 
 #ifdef __cplusplus
 }

@@ -362,6 +362,32 @@ __global__ void k_pack_weights(const float* __restrict__ w, int Cout, int Cin, i
   }
 }
 
+// the same for up to GPACK_MAX weights in one launch (blockIdx.y = item): the Linears of the transformer models whose operands are
+// not in the patch format
+#define GPACK_MAX 32
+struct GPackItem { const float* w; float* wf; float* wd; int Cout, Cin, taps, CpiF, KpF, N16F, CpoD, KpD, N16D; };
+struct GPackBatch { GPackItem it[GPACK_MAX]; };
+__global__ void k_pack_weights_many(GPackBatch pb) {
+  const GPackItem& q = pb.it[blockIdx.y];
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nF = q.N16F * q.KpF;
+  if (q.wf != nullptr && idx < nF) {
+    const int n = idx / q.KpF, k = idx - n * q.KpF;
+    const int tap = k / q.CpiF, c = k - tap * q.CpiF;
+    float v = 0.f;
+    if (n < q.Cout && tap < q.taps && c < q.Cin) v = q.w[((size_t)n * q.Cin + c) * q.taps + tap];
+    q.wf[idx] = v;
+  }
+  const int nD = q.N16D * q.KpD;
+  if (q.wd != nullptr && idx < nD) {
+    const int n = idx / q.KpD, k = idx - n * q.KpD;
+    const int tap = k / q.CpoD, co = k - tap * q.CpoD;
+    float v = 0.f;
+    if (n < q.Cin && tap < q.taps && co < q.Cout) v = q.w[((size_t)co * q.Cin + n) * q.taps + tap];
+    q.wd[idx] = v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -469,12 +495,28 @@ extern "C" int md_conv_pack_weights_batch(int32_t n, const MdConvDesc* descs, co
   }
   int rc = patch_pack_batch(2 * n, dp.data(), dg.data(), wsrc.data(), outs.data(), handled.data(), (hipStream_t)stream);
   if (rc) return rc;
+  GPackBatch gb; int cnt = 0, maxtot = 0;
+  auto flush = [&]() -> int {
+    if (!cnt) return MD_OK;
+    MD_KLAUNCH(k_pack_weights_many, dim3(md_cdiv(maxtot, 256), cnt), dim3(256), 0, (hipStream_t)stream, gb);
+    MD_CHECK_LAUNCH();
+    cnt = 0; maxtot = 0;
+    return MD_OK;
+  };
   for (int i = 0; i < n; ++i) {
     float* f = handled[2 * i] ? nullptr : wf[i];
     float* d = handled[2 * i + 1] ? nullptr : wd[i];
-    if (f || d) { rc = md_conv_pack_weights(&descs[i], w[i], f, d, stream); if (rc) return rc; }
+    if (!f && !d) continue;
+    const Geom gf = geom_fwd(&descs[i]), gd = geom_dgrad(&descs[i]);
+    GPackItem& q = gb.it[cnt++];
+    q.w = w[i]; q.wf = f; q.wd = d; q.Cout = descs[i].Cout; q.Cin = descs[i].Cin; q.taps = descs[i].kt * descs[i].kh * descs[i].kw;
+    q.CpiF = gf.Cpi; q.KpF = gf.Kp; q.N16F = gf.N16; q.CpoD = gd.Cpi; q.KpD = gd.Kp; q.N16D = gd.N16;
+    const int nF = f ? gf.N16 * gf.Kp : 0, nD = d ? gd.N16 * gd.Kp : 0;
+    if (nF > maxtot) maxtot = nF;
+    if (nD > maxtot) maxtot = nD;
+    if (cnt == GPACK_MAX) { rc = flush(); if (rc) return rc; }
   }
-  return MD_OK;
+  return flush();
 }
 
 extern "C" int32_t md_conv_fwd_stat_blocks(const MdConvDesc* d) {

@@ -18,6 +18,7 @@ from typing import Union
 import torch
 import torch.nn as nn
 
+from .. import ops
 from ._unit import (AddLayerNormFunction, AttentionFunction, EluFunction, GeluFunction, PatchEmbedFunction, ResidualLayerNormFunction,
                     _ChannelBias, _SeqSum, dropout, linear_bias_gelu_dropout, linear_wb)
 
@@ -232,10 +233,11 @@ class ViViT(_ViViTBase):
         return _rows(EluFunction.apply(x, self.mlp[2].alpha), self.mlp[3])
 
     def forward(self, x: torch.Tensor):
-        return self._head(self._encode(x))
+        with ops.prepacked(self):          # the GEMM operands of every Linear packed by one batched call (36 tiny launches per step otherwise)
+            return self._head(self._encode(x))
 
     def encode(self, x: torch.Tensor):
-        with torch.no_grad():
+        with torch.no_grad(), ops.prepacked(self):
             return self._encode(x)
 
 
@@ -248,4 +250,5 @@ class ViViTEncoder(_ViViTBase):
                            embedd_dropout, scale_dim)
 
     def forward(self, x: torch.Tensor):
-        return self._encode(x)
+        with ops.prepacked(self):
+            return self._encode(x)

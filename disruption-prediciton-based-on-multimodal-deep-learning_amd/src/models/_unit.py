@@ -805,7 +805,7 @@ class LinearRowsFunction(torch.autograd.Function):
         d = ops.make_desc(1, 1, 1, rows, Din, Dout, (1, 1, 1), (1, 1, 1), (0, 0, 0))
         if Din % 4:
             x = torch.nn.functional.pad(x, (0, ops.cpad(Din) - Din))
-        wf, wd = ops.pack_weights(d, w[:, :, None, None, None].contiguous(), want_dgrad=True)
+        wf, wd = ops.pack_weights(d, w[:, :, None, None, None].contiguous(), want_dgrad=True, owner=w)
         y, _ = ops.conv_fwd(d, ops.view(x), wf, x.device, want_stats=False)
         ctx.d = d
         ctx.save_for_backward(x, wd)

@@ -107,6 +107,7 @@ def from_channels_last(x: torch.Tensor, channels: int) -> torch.Tensor:
 _pack_stream = [None]   # the stream the packs of the active prepacked() scope were made on
 _pack_memo = {}        # id(weight) -> (weak reference to the weight, descriptor fields, want_dgrad)
 _pack_ready = None     # inside prepacked(): id(weight) -> (descriptor fields, wf, wd)
+_PREPACK_OFF = os.environ.get("MD_PREPACK") == "0"      # A/B switch: every unit packs its own operands again
 
 
 def _desc_key(d: N.MdConvDesc):
@@ -124,7 +125,7 @@ class prepacked:
     def __enter__(self):
         global _pack_ready
         self.outer = _pack_ready
-        if self.outer is not None or not _pack_memo:
+        if self.outer is not None or not _pack_memo or _PREPACK_OFF:
             return self
         items = []
         for wid, (ref, key, wd) in list(_pack_memo.items()):
@@ -160,11 +161,17 @@ class prepacked:
         return False
 
 
-def pack_weights(d: N.MdConvDesc, w: torch.Tensor, want_dgrad: bool = True):
+def pack_weights(d: N.MdConvDesc, w: torch.Tensor, want_dgrad: bool = True, owner: Optional[torch.Tensor] = None):
+    """``owner``: the Parameter whose memory ``w`` is a reshaped view of (a Linear's (Dout, Din) weight handed over as a
+    (Dout, Din, 1, 1, 1) convolution weight): the batched pre-pack of ``prepacked`` is remembered and looked up under ITS identity."""
     require_cuda(w); f32(w)
     key = _desc_key(d)
+    if owner is not None and not (isinstance(owner, torch.nn.Parameter) and owner.is_contiguous() and owner.numel() == w.numel()
+                                  and owner.data_ptr() == w.data_ptr()):
+        owner = None
+    ident = w if owner is None else owner
     if _pack_ready is not None:
-        hit = _pack_ready.get(id(w))
+        hit = _pack_ready.get(id(ident))
         if hit is not None and hit[0] == key and (hit[2] is not None or not want_dgrad):
             cur = torch.cuda.current_stream(w.device)
             if cur != _pack_stream[0]:                     # a branch on a side stream (src/utils/streams.py) reads packs made on another
@@ -172,8 +179,8 @@ def pack_weights(d: N.MdConvDesc, w: torch.Tensor, want_dgrad: bool = True):
                 if hit[2] is not None:
                     hit[2].record_stream(cur)
             return hit[1], (hit[2] if want_dgrad else None)
-    if isinstance(w, torch.nn.Parameter):                 # (views and temporaries have no stable identity)
-        _pack_memo[id(w)] = (weakref.ref(w), key, bool(want_dgrad))
+    if isinstance(ident, torch.nn.Parameter):             # (views and temporaries have no stable identity)
+        _pack_memo[id(ident)] = (weakref.ref(ident), key, bool(want_dgrad))
     L = N.lib()
     wf = torch.empty(L.md_conv_wpack_fwd_floats(C.byref(d)), device=w.device, dtype=torch.float32)
     wd = torch.empty(L.md_conv_wpack_dgrad_floats(C.byref(d)), device=w.device, dtype=torch.float32) if want_dgrad else None

@@ -161,6 +161,23 @@ class prepacked:
         return False
 
 
+class own_packs:
+    """Hide the packs of an enclosing ``prepacked`` scope: a branch whose launches are RECORDED (src/utils/graphed.py::GraphedBranch)
+    must pack its operands itself, inside the recording -- the buffers of the enclosing scope are temporaries of one eager forward,
+    and a graph that baked their addresses would read whatever lives there at replay time."""
+
+    def __enter__(self):
+        global _pack_ready
+        self.outer = _pack_ready
+        _pack_ready = None
+        return self
+
+    def __exit__(self, *exc):
+        global _pack_ready
+        _pack_ready = self.outer
+        return False
+
+
 def pack_weights(d: N.MdConvDesc, w: torch.Tensor, want_dgrad: bool = True, owner: Optional[torch.Tensor] = None):
     """``owner``: the Parameter whose memory ``w`` is a reshaped view of (a Linear's (Dout, Din) weight handed over as a
     (Dout, Din, 1, 1, 1) convolution weight): the batched pre-pack of ``prepacked`` is remembered and looked up under ITS identity."""

@@ -244,7 +244,9 @@ class GraphedBranch:
             self.fn = fn
 
         def forward(self, *xs):
-            return self.fn(*xs)
+            from .. import ops
+            with ops.own_packs():              # the recorded branch packs its own GEMM operands (see ops.own_packs)
+                return self.fn(*xs)
 
     def __init__(self, owner: torch.nn.Module, fn: Callable, example_inputs: Sequence[torch.Tensor]):
         self.noise_layers = [mod for mod in owner.modules() if type(mod).__name__ == "NoiseLayer"]

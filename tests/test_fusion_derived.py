@@ -248,8 +248,19 @@ def test_graphed_0d_branch_matches_the_eager_step():
         return res, used, state
 
     ref, used0, st0 = run(False)
-    got, used1, st1 = run(True)
+    import warnings
+    warn_always = torch.is_warn_always_enabled()
+    torch.set_warn_always(True)
+    try:
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            got, used1, st1 = run(True)
+    finally:
+        torch.set_warn_always(warn_always)
     assert used0 is None and used1 not in (None, False)
+    # the replayed steps feed the parameters' AccumulateGrad nodes on the stream those nodes belong to: no cross-stream hand-over per
+    # step (PyTorch says so with a warning when there is one)
+    assert not [w for w in caught if "AccumulateGrad node's stream does not match" in str(w.message)], [str(w.message)[:120] for w in caught]
     # buffers too: the probe and the warm-up iterations of the capture must not leave extra BatchNorm momentum updates behind, and
     # the replays must advance num_batches_tracked exactly as the eager steps do (graphed.py)
     assert st0.keys() == st1.keys()

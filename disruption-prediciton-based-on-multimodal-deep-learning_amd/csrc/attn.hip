@@ -4,6 +4,7 @@
 // per (batch, head); everything fixed-order fp32.
 #include "common.h"
 #include "patch_common.h"
+#include "philox.h"
 #include <map>
 #include <mutex>
 
@@ -999,6 +1000,142 @@ extern "C" int md_elu(const float* x, const float* dy, float alpha, int64_t n, f
   return MD_OK;
 }
 
+extern "C" size_t md_add_layernorm_bwd_scratch_floats(int64_t rows, int32_t D);
+// One step of a pre-norm residual stream with the branch's tail folded in (ViViT.py:31-46,85-91,108-111): the branch ends in
+// Linear (+ bias) -> nn.Dropout, then  s = branch + stream,  h = LayerNorm(s).  y is the Linear's raw product; this pass applies bias and
+// the (regenerated, philox.h) dropout decisions on the way in instead of two elementwise passes over y before it:
+//   s = (y + bias) * keep-decision * scale + stream;  h = LayerNorm(s) * gamma + beta.
+// Four consecutive features per lane (one Philox call), L = 16 / 32 / 64 lanes per row, row sums by shuffles inside the L lanes.
+template <int L>
+__device__ __forceinline__ float lanes_sum(float v) {
+#pragma unroll
+  for (int o = L / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+template <int L>
+__global__ __launch_bounds__(256) void k_branch_ln_fwd(const float* __restrict__ y, const float* __restrict__ bias, const int64_t* __restrict__ key,
+                                                      int tag, float keep, const float* __restrict__ stream_in, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, int64_t rows, int D4, float eps, float* __restrict__ out,
+                                                      float* __restrict__ xhat, float* __restrict__ rstd, float* __restrict__ sum_out) {
+  constexpr int RPB = 256 / L;                           // rows per workgroup
+  const int c4 = threadIdx.x % L;
+  const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / L;
+  const bool act = row < rows && c4 < D4;
+  const int64_t i4 = act ? row * D4 + c4 : 0;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (act) {
+    const float4 a = ((const float4*)y)[i4], r = ((const float4*)stream_in)[i4];
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) b = ((const float4*)bias)[c4];
+    float h[4] = {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
+    if (key) {
+      float m[4];
+      md_drop_keep4(md_drop_key(key), tag, i4, keep, m);
+      const float sc = 1.f / keep;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h[e] = h[e] * m[e] * sc;
+    }
+    v[0] = h[0] + r.x; v[1] = h[1] + r.y; v[2] = h[2] + r.z; v[3] = h[3] + r.w;
+  }
+  const float D = (float)(D4 * 4);
+  const float mean = lanes_sum<L>((v[0] + v[1]) + (v[2] + v[3])) / D;
+  float d[4], q = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { d[e] = act ? v[e] - mean : 0.f; q += d[e] * d[e]; }
+  const float var = lanes_sum<L>(q) / D;
+  const float rs = 1.f / sqrtf(var + eps);
+  if (act) {
+    const float4 g = ((const float4*)gamma)[c4], bt = ((const float4*)beta)[c4];
+    const float4 xh = make_float4(d[0] * rs, d[1] * rs, d[2] * rs, d[3] * rs);
+    ((float4*)xhat)[i4] = xh;
+    ((float4*)out)[i4] = make_float4(xh.x * g.x + bt.x, xh.y * g.y + bt.y, xh.z * g.z + bt.z, xh.w * g.w + bt.w);
+    ((float4*)sum_out)[i4] = make_float4(v[0], v[1], v[2], v[3]);
+    if (c4 == 0) rstd[row] = rs;
+  }
+}
+// dstream = rstd * (g - mean(g) - xhat * mean(g * xhat)) + dres,  g = dout * gamma   (gradient of the sum: what the residual stream
+// carries on); dbranch = dstream * keep-decision * scale (gradient of the Linear's raw product; the bias gradient is its column sum).
+template <int L>
+__global__ __launch_bounds__(256) void k_branch_ln_bwd(const float* __restrict__ dout, const float* __restrict__ gamma, const float* __restrict__ xhat,
+                                                      const float* __restrict__ rstd, const float* __restrict__ dres, const int64_t* __restrict__ key,
+                                                      int tag, float keep, int64_t rows, int D4, float* __restrict__ dstream,
+                                                      float* __restrict__ dbranch) {
+  constexpr int RPB = 256 / L;
+  const int c4 = threadIdx.x % L;
+  const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / L;
+  const bool act = row < rows && c4 < D4;
+  const int64_t i4 = act ? row * D4 + c4 : 0;
+  float g[4] = {0.f, 0.f, 0.f, 0.f}, xh[4] = {0.f, 0.f, 0.f, 0.f};
+  if (act) {
+    const float4 a = ((const float4*)dout)[i4], gm = ((const float4*)gamma)[c4], x = ((const float4*)xhat)[i4];
+    g[0] = a.x * gm.x; g[1] = a.y * gm.y; g[2] = a.z * gm.z; g[3] = a.w * gm.w;
+    xh[0] = x.x; xh[1] = x.y; xh[2] = x.z; xh[3] = x.w;
+  }
+  const float D = (float)(D4 * 4);
+  const float m1 = lanes_sum<L>((g[0] + g[1]) + (g[2] + g[3])) / D;
+  const float m2 = lanes_sum<L>((g[0] * xh[0] + g[1] * xh[1]) + (g[2] * xh[2] + g[3] * xh[3])) / D;
+  if (!act) return;
+  const float rs = rstd[row];
+  float r[4] = {0.f, 0.f, 0.f, 0.f};
+  if (dres) { const float4 t = ((const float4*)dres)[i4]; r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w; }
+  float dx[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) dx[e] = rs * (g[e] - m1 - xh[e] * m2) + r[e];
+  ((float4*)dstream)[i4] = make_float4(dx[0], dx[1], dx[2], dx[3]);
+  if (key) {
+    float m[4];
+    md_drop_keep4(md_drop_key(key), tag, i4, keep, m);
+    const float sc = 1.f / keep;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dx[e] = dx[e] * m[e] * sc;
+  }
+  ((float4*)dbranch)[i4] = make_float4(dx[0], dx[1], dx[2], dx[3]);
+}
+extern "C" int md_branch_layernorm_supported(int64_t rows, int32_t D) { return rows > 0 && D > 0 && (D & 3) == 0 && D <= 256 ? 1 : 0; }
+extern "C" int md_branch_layernorm_fwd(const float* y, const float* bias, const int64_t* key, int32_t tag, float keep, const float* stream_in,
+                                       const float* gamma, const float* beta, int64_t rows, int32_t D, float eps, float* out, float* xhat,
+                                       float* rstd, float* sum_out, void* stream) {
+  if (!y || !stream_in || !gamma || !beta || !out || !xhat || !rstd || !sum_out) return MD_ERR_NULL;
+  if (!md_branch_layernorm_supported(rows, D) || (key && !(keep > 0.f && keep <= 1.f))) return MD_ERR_BAD_SHAPE;
+  if ((((uintptr_t)y | (uintptr_t)bias | (uintptr_t)stream_in | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out | (uintptr_t)xhat |
+        (uintptr_t)sum_out) & 15) != 0) return MD_ERR_BAD_SHAPE;
+  const int D4 = D / 4;
+  hipStream_t s = (hipStream_t)stream;
+#define BLN_FWD(L_) MD_KLAUNCH(k_branch_ln_fwd<L_>, dim3((unsigned)((rows + 256 / L_ - 1) / (256 / L_))), dim3(256), 0, s, y, bias, key, tag, keep, \
+                               stream_in, gamma, beta, rows, D4, eps, out, xhat, rstd, sum_out)
+  if (D4 <= 16) BLN_FWD(16); else if (D4 <= 32) BLN_FWD(32); else BLN_FWD(64);
+#undef BLN_FWD
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+extern "C" int md_branch_layernorm_bwd(const float* dout, const float* gamma, const float* xhat, const float* rstd, const float* dres,
+                                       const int64_t* key, int32_t tag, float keep, int64_t rows, int32_t D, float* dstream, float* dbranch,
+                                       float* dgamma, float* dbeta, float* scratch, void* stream) {
+  if (!dout || !gamma || !xhat || !rstd || !dstream || !dbranch || !dgamma || !dbeta) return MD_ERR_NULL;
+  if (!md_branch_layernorm_supported(rows, D) || (key && !(keep > 0.f && keep <= 1.f))) return MD_ERR_BAD_SHAPE;
+  if ((((uintptr_t)dout | (uintptr_t)gamma | (uintptr_t)xhat | (uintptr_t)dres | (uintptr_t)dstream | (uintptr_t)dbranch) & 15) != 0) return MD_ERR_BAD_SHAPE;
+  const bool chunked = md_add_layernorm_bwd_scratch_floats(rows, D) != 0;
+  if (chunked && !scratch) return MD_ERR_WORKSPACE;
+  const int D4 = D / 4;
+  hipStream_t s = (hipStream_t)stream;
+#define BLN_BWD(L_) MD_KLAUNCH(k_branch_ln_bwd<L_>, dim3((unsigned)((rows + 256 / L_ - 1) / (256 / L_))), dim3(256), 0, s, dout, gamma, xhat, rstd, dres, \
+                               key, tag, keep, rows, D4, dstream, dbranch)
+  if (D4 <= 16) BLN_BWD(16); else if (D4 <= 32) BLN_BWD(32); else BLN_BWD(64);
+#undef BLN_BWD
+  MD_CHECK_LAUNCH();
+  if (!chunked) {
+    MD_KLAUNCH(k_ln_param_grad, dim3(md_cdiv(D, 64), 1), dim3(256), 0, s, dout, xhat, (int)rows, D, dgamma, dbeta);
+    MD_CHECK_LAUNCH();
+  } else {
+    float* pg = scratch; float* pb = scratch + (size_t)LN_CHUNKS * D;
+    MD_KLAUNCH(k_ln_param_grad, dim3(md_cdiv(D, 64), LN_CHUNKS), dim3(256), 0, s, dout, xhat, (int)rows, D, pg, pb);
+    MD_CHECK_LAUNCH();
+    MD_KLAUNCH(k_ln_param_sum, dim3(md_cdiv(D, 16)), dim3(256), 0, s, (const float*)pg, (const float*)pb, LN_CHUNKS, D, dgamma, dbeta);
+    MD_CHECK_LAUNCH();
+  }
+  return MD_OK;
+}
+
 extern "C" int md_add_layernorm_fwd(const float* a, const float* b, const float* gamma, const float* beta, int64_t rows, int32_t D,
                                     float eps, float* out, float* xhat, float* rstd, float* sum_out, void* stream) {
   if (!a || !gamma || !beta || !out || !xhat || !rstd) return MD_ERR_NULL;
@@ -1189,6 +1326,42 @@ extern "C" int md_bias_gelu_drop(const float* x, const float* bias, const float*
   int64_t blocks = (n4 + 255) / 256; if (blocks > 8192) blocks = 8192;
   if (dout) MD_KLAUNCH(k_bias_gelu_drop<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, bias, mask, dout, scale, kind, n4, C / 4, out);
   else MD_KLAUNCH(k_bias_gelu_drop<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, bias, mask, dout, scale, kind, n4, C / 4, out);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+// The same pass with the dropout decisions regenerated from a counter-based generator instead of read from a mask tensor (philox.h): at
+// cfg3 the FeedForward hidden activation is 68 MB, and its mask cost one 68 MB write (torch's bernoulli_) and two 68 MB reads per layer.
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_bias_gelu_drop_ctr(const float* __restrict__ x, const float* __restrict__ bias, const int64_t* __restrict__ state,
+                                                           int tag, float keep, const float* __restrict__ dout, float scale, int kind, int64_t n4,
+                                                           int c4, float* __restrict__ out) {
+  const MdDropKey key = md_drop_key(state);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 a = ((const float4*)x)[i], b = ((const float4*)bias)[i % c4];
+    const float h[4] = {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
+    float m[4], g[4] = {0.f, 0.f, 0.f, 0.f}, r[4];
+    md_drop_keep4(key, tag, i, keep, m);
+    if (BWD) { const float4 gg = ((const float4*)dout)[i]; g[0] = gg.x; g[1] = gg.y; g[2] = gg.z; g[3] = gg.w; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float y, d;
+      gelu_val(h[e], kind, y, d);
+      if (BWD) r[e] = (g[e] * m[e] * scale) * d;
+      else r[e] = y * m[e] * scale;
+    }
+    ((float4*)out)[i] = make_float4(r[0], r[1], r[2], r[3]);
+  }
+}
+extern "C" int md_bias_gelu_drop_ctr(const float* x, const float* bias, const int64_t* state, int32_t tag, float keep, const float* dout,
+                                     float scale, int32_t kind, int64_t rows, int32_t C, float* out, void* stream) {
+  if (!x || !bias || !state || !out) return MD_ERR_NULL;
+  if (rows <= 0 || C <= 0 || (C & 3) || (kind != 0 && kind != 1) || !(keep > 0.f && keep <= 1.f)) return MD_ERR_BAD_SHAPE;
+  if ((((uintptr_t)x | (uintptr_t)bias | (uintptr_t)dout | (uintptr_t)out) & 15) != 0) return MD_ERR_BAD_SHAPE;
+  const int64_t n4 = rows * (C / 4);
+  int64_t blocks = (n4 + 255) / 256; if (blocks > 8192) blocks = 8192;
+  if (dout) MD_KLAUNCH(k_bias_gelu_drop_ctr<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, bias, state, tag, keep, dout, scale, kind, n4, C / 4, out);
+  else MD_KLAUNCH(k_bias_gelu_drop_ctr<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, bias, state, tag, keep, dout, scale, kind, n4, C / 4, out);
   MD_CHECK_LAUNCH();
   return MD_OK;
 }

@@ -2,6 +2,7 @@
 //   SwishEfficient (src/models/resnet.py:70-81): y = x * sigmoid(x); dx = dy * s * (1 + x * (1 - s)), s = sigmoid(x)
 //   NoiseLayer (src/models/NoiseLayer.py:5-16, training branch): out = x + (mean + noise * std)
 #include "common.h"
+#include "philox.h"
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
@@ -543,6 +544,34 @@ extern "C" int md_seq_sum_bwd(const float* dout, int32_t B, int32_t S, int32_t D
   if (!dout || !dx) return MD_ERR_NULL;
   if (B <= 0 || S <= 0 || D <= 0) return MD_ERR_BAD_SHAPE;
   MD_KLAUNCH(k_small<2>, dim3(elem_blocks((int64_t)B * S * D * 4)), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, dout, scale, B, S, D, dx);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+// out[i] = x[i] * scale where element i is kept, 0 otherwise; kept <=> Philox word (state, tag, i) < keep (philox.h).  Forward and
+// backward of a mask-free nn.Dropout are this one kernel (on the activation, then on the gradient).
+__global__ __launch_bounds__(256) void k_dropout_ctr(const float* __restrict__ x, const int64_t* __restrict__ state, int tag, float keep,
+                                                    float scale, int64_t n, int vec, float* __restrict__ out) {
+  const MdDropKey key = md_drop_key(state);
+  const int64_t n4 = (n + 3) >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float m[4];
+    md_drop_keep4(key, tag, i, keep, m);
+    if (vec) {
+      const float4 a = ((const float4*)x)[i];
+      ((float4*)out)[i] = make_float4(a.x * m[0] * scale, a.y * m[1] * scale, a.z * m[2] * scale, a.w * m[3] * scale);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (i * 4 + e < n) out[i * 4 + e] = x[i * 4 + e] * m[e] * scale;
+    }
+  }
+}
+extern "C" int md_dropout_ctr(const float* x, const int64_t* state, int32_t tag, float keep, float scale, int64_t n, float* out, void* stream) {
+  if (!x || !state || !out) return MD_ERR_NULL;
+  if (n <= 0 || !(keep > 0.f && keep <= 1.f)) return MD_ERR_BAD_SHAPE;
+  const int vec = (n & 3) == 0 && ((((uintptr_t)x | (uintptr_t)out) & 15) == 0);
+  MD_KLAUNCH(k_dropout_ctr, dim3(elem_blocks((n + 3) >> 2)), dim3(256), 0, (hipStream_t)stream, x, state, tag, keep, scale, n, vec, out);
   MD_CHECK_LAUNCH();
   return MD_OK;
 }

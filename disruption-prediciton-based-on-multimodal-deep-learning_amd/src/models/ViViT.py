@@ -19,8 +19,8 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ._unit import (AddLayerNormFunction, AttentionFunction, EluFunction, GeluFunction, PatchEmbedFunction, ResidualLayerNormFunction,
-                    _ChannelBias, _SeqSum, dropout, linear_bias_gelu_dropout, linear_wb)
+from ._unit import (AddLayerNormFunction, AttentionFunction, EluFunction, GeluFunction, LinearRowsFunction, PatchEmbedFunction,
+                    ResidualLayerNormFunction, _ChannelBias, _SeqSum, branch_residual_layernorm, dropout, linear_bias_gelu_dropout, linear_wb)
 
 
 def _layer_norm(x, norm: nn.LayerNorm):
@@ -69,11 +69,19 @@ class FeedForward(nn.Module):
             nn.Dropout(dropout)
         )
 
-    def forward(self, x: torch.Tensor):
+    def _hidden(self, x: torch.Tensor):
         lin = self.net[0]
-        h = linear_bias_gelu_dropout(x.reshape(-1, x.shape[-1]), lin.weight, lin.bias, self.net[2].p, self.net[2].training, 0)
-        h = h.reshape(x.shape[:-1] + (lin.out_features,))
+        return linear_bias_gelu_dropout(x.reshape(-1, x.shape[-1]), lin.weight, lin.bias, self.net[2].p, self.net[2].training, 0)
+
+    def forward(self, x: torch.Tensor):
+        h = self._hidden(x).reshape(x.shape[:-1] + (self.net[0].out_features,))
         return dropout(_rows(h, self.net[3]), self.net[4].p, self.net[4].training)
+
+    def branch_tail(self, x: torch.Tensor):
+        """The branch up to the raw product of its last Linear: (y (rows, dim), bias, dropout p, training) -- Transformer.forward folds
+        bias, dropout, the residual add and the next LayerNorm into one pass (branch_residual_layernorm)."""
+        lin = self.net[3]
+        return LinearRowsFunction.apply(self._hidden(x), lin.weight), lin.bias, self.net[4].p, self.net[4].training
 
 
 class Attention(nn.Module):
@@ -103,6 +111,14 @@ class Attention(nn.Module):
             return out
         return dropout(_rows(out, self.to_out[0]), self.to_out[1].p, self.to_out[1].training)
 
+    def branch_tail(self, x: torch.Tensor):
+        """As FeedForward.branch_tail; None when there is no output projection (then forward() is the whole branch)."""
+        if isinstance(self.to_out, nn.Identity):
+            return None
+        out = AttentionFunction.apply(_rows(x, self.to_qkv), None, self.n_heads, None, True)
+        lin = self.to_out[0]
+        return LinearRowsFunction.apply(out.reshape(-1, out.shape[-1]), lin.weight), lin.bias, self.to_out[1].p, self.to_out[1].training
+
 
 class Transformer(nn.Module):
     def __init__(self, dim: int, depth: int, n_heads: int, d_head: int, mlp_dim: int, dropout: float = 0.0):
@@ -123,8 +139,12 @@ class Transformer(nn.Module):
         res = x
         h = _layer_norm(res, norms[0])
         for i, (attn, ff) in enumerate(self.layers):
-            res, h = ResidualLayerNormFunction.apply(attn.fn(h), res, norms[2 * i + 1].weight, norms[2 * i + 1].bias, norms[2 * i + 1].eps)
-            res, h = ResidualLayerNormFunction.apply(ff.fn(h), res, norms[2 * i + 2].weight, norms[2 * i + 2].bias, norms[2 * i + 2].eps)
+            for blk, norm in ((attn.fn, norms[2 * i + 1]), (ff.fn, norms[2 * i + 2])):
+                tail = blk.branch_tail(h) if hasattr(blk, "branch_tail") else None
+                if tail is None:
+                    res, h = ResidualLayerNormFunction.apply(blk(h), res, norm.weight, norm.bias, norm.eps)
+                else:           # Linear bias + dropout + residual add + the next LayerNorm in one pass
+                    res, h = branch_residual_layernorm(tail[0], tail[1], tail[2], tail[3], res, norm)
         return h
 
 
@@ -233,7 +253,8 @@ class ViViT(_ViViTBase):
         return _rows(EluFunction.apply(x, self.mlp[2].alpha), self.mlp[3])
 
     def forward(self, x: torch.Tensor):
-        with ops.prepacked(self):          # the GEMM operands of every Linear packed by one batched call (36 tiny launches per step otherwise)
+        # the GEMM operands of every Linear packed by one batched call (36 tiny launches per step otherwise); dropout without mask tensors
+        with ops.prepacked(self), ops.counter_dropout(x.device, self.training):
             return self._head(self._encode(x))
 
     def encode(self, x: torch.Tensor):
@@ -250,5 +271,5 @@ class ViViTEncoder(_ViViTBase):
                            embedd_dropout, scale_dim)
 
     def forward(self, x: torch.Tensor):
-        with ops.prepacked(self):
+        with ops.prepacked(self), ops.counter_dropout(x.device, self.training):
             return self._encode(x)

@@ -723,6 +723,81 @@ class ResidualLayerNormFunction(torch.autograd.Function):
         return dx, dx, dgamma, dbeta, None
 
 
+class BranchResidualLayerNormFunction(torch.autograd.Function):
+    """(s, h) = (dropout(y + bias) + res, LayerNorm(s)): ResidualLayerNormFunction with the branch's Linear bias and nn.Dropout folded
+    into the same pass (md_branch_layernorm_*; reference ViViT.py:31-46,85-91,108-111).  y is the Linear's raw product; ``site`` =
+    (key tensor, tag) of the dropout call site (ops.dropout_site()) or None for no dropout."""
+
+    @staticmethod
+    def forward(ctx, y, bias, res, gamma, beta, eps, site, keep):
+        y = ops.f32(y).contiguous(); res = ops.f32(res).contiguous()
+        ops.require_cuda(y, bias, res, gamma, beta)
+        ctx.set_materialize_grads(False)
+        D = y.shape[-1]
+        rows = y.numel() // D
+        bb = None if bias is None else ops.f32(bias).contiguous()
+        key, tag = site if site is not None else (None, 0)
+        out = torch.empty_like(y); xhat = torch.empty_like(y); rstd = torch.empty(rows, device=y.device); s = torch.empty_like(y)
+        N.check(N.lib().md_branch_layernorm_fwd(ops._p(y), ops._p(bb), ops._p(key), int(tag), float(keep), ops._p(res), ops._p(gamma.contiguous()),
+                                                ops._p(beta.contiguous()), rows, D, float(eps), ops._p(out), ops._p(xhat), ops._p(rstd), ops._p(s),
+                                                ops._stream()), "md_branch_layernorm_fwd")
+        ctx.save_for_backward(gamma, xhat, rstd)
+        ctx.key, ctx.tag, ctx.keep, ctx.has_bias = key, int(tag), float(keep), bias is not None
+        return s, out
+
+    @staticmethod
+    def backward(ctx, ds, dout):
+        gamma, xhat, rstd = ctx.saved_tensors
+        D = xhat.shape[-1]
+        rows = xhat.numel() // D
+        dev = xhat.device
+        if dout is None:
+            # the normalised branch was not used: only the stream's gradient flows; the branch's is that gradient through the dropout
+            dsum = ops.f32(ds).contiguous()
+            if ctx.key is None:
+                dy = dsum
+            else:
+                dy = torch.empty_like(dsum)
+                N.check(N.lib().md_dropout_ctr(ops._p(dsum), ops._p(ctx.key), ctx.tag, ctx.keep, 1.0 / ctx.keep, dsum.numel(), ops._p(dy),
+                                               ops._stream()), "md_dropout_ctr")
+            dgamma, dbeta = torch.zeros_like(gamma), torch.zeros_like(gamma)
+        else:
+            g = ops.f32(dout).contiguous()
+            dres = None if ds is None else ops.f32(ds).contiguous()
+            dsum = torch.empty_like(g); dy = torch.empty_like(g)
+            dgamma = torch.empty(D, device=dev); dbeta = torch.empty(D, device=dev)
+            ns = N.lib().md_add_layernorm_bwd_scratch_floats(rows, D)
+            scratch = torch.empty(ns, device=dev) if ns else None
+            N.check(N.lib().md_branch_layernorm_bwd(ops._p(g), ops._p(gamma.contiguous()), ops._p(xhat), ops._p(rstd), ops._p(dres), ops._p(ctx.key),
+                                                    ctx.tag, ctx.keep, rows, D, ops._p(dsum), ops._p(dy), ops._p(dgamma), ops._p(dbeta),
+                                                    ops._p(scratch), ops._stream()), "md_branch_layernorm_bwd")
+        db = None
+        if ctx.has_bias:
+            db = torch.empty(D, device=dev)
+            ns = N.lib().md_channel_bias_bwd_scratch_floats(rows, D, 1)
+            scratch = torch.empty(ns, device=dev) if ns else None
+            N.check(N.lib().md_channel_bias_bwd(ops._p(dy), rows, D, 1, ops._p(db), ops._p(scratch), ops._stream()), "md_channel_bias_bwd")
+        return dy, db, dsum, dgamma, dbeta, None, None, None
+
+
+def branch_residual_layernorm(y2d, bias, p: float, training: bool, res, norm):
+    """One residual step of a pre-norm transformer block whose branch ends in Linear (raw product y2d, its bias) -> Dropout(p):
+    returns (new stream, LayerNorm(new stream)) shaped like ``res``.  Fused where md_branch_layernorm_* applies, composed otherwise."""
+    D = res.shape[-1]
+    rows = res.numel() // D
+    drop = training and p > 0.0
+    site = ops.dropout_site() if (drop and res.is_cuda) else None
+    if res.is_cuda and N.lib().md_branch_layernorm_supported(rows, D) and (not drop or site is not None):
+        s, h = BranchResidualLayerNormFunction.apply(y2d.reshape(res.shape), bias, res, norm.weight, norm.bias, norm.eps, site, 1.0 - p if drop else 1.0)
+        return s, h
+    y = y2d if bias is None else _ChannelBias.apply(y2d.contiguous()[:, :, None], bias)[:, :, 0]
+    if drop:
+        keep = 1.0 - p
+        y = CtrDropoutFunction.apply(y, site[0], site[1], keep) if site is not None else \
+            _MaskScale.apply(y, torch.empty_like(y).bernoulli_(keep), 1.0 / keep)
+    return ResidualLayerNormFunction.apply(y.reshape(res.shape), res, norm.weight, norm.bias, norm.eps)
+
+
 class AttentionFunction(torch.autograd.Function):
     """softmax(q k^T / sqrt(dh) + mask) [* dropout] v per head   (md_attention_*).  qkv (S, B, 3D) -> (S, B, D), or with
     batch_first (B, S, 3D) -> (B, S, D)."""
@@ -879,6 +954,58 @@ class BiasGeluDropFunction(torch.autograd.Function):
         return dx, db, None, None, None
 
 
+class CtrDropoutFunction(torch.autograd.Function):
+    """Inverted dropout whose decisions are regenerated, not stored (md_dropout_ctr): backward = the same call on the gradient."""
+
+    @staticmethod
+    def forward(ctx, x, state, tag, keep):
+        x = ops.f32(x).contiguous()
+        ops.require_cuda(x, state)
+        out = torch.empty_like(x)
+        N.check(N.lib().md_dropout_ctr(ops._p(x), ops._p(state), int(tag), float(keep), 1.0 / float(keep), x.numel(), ops._p(out), ops._stream()),
+                "md_dropout_ctr")
+        ctx.state, ctx.tag, ctx.keep = state, int(tag), float(keep)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        g = ops.f32(dout).contiguous()
+        dx = torch.empty_like(g)
+        N.check(N.lib().md_dropout_ctr(ops._p(g), ops._p(ctx.state), ctx.tag, ctx.keep, 1.0 / ctx.keep, g.numel(), ops._p(dx), ops._stream()),
+                "md_dropout_ctr")
+        return dx, None, None, None
+
+
+class BiasGeluDropCtrFunction(torch.autograd.Function):
+    """gelu(x + bias) * keep-decision * scale over rows with the decisions regenerated (md_bias_gelu_drop_ctr)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, state, tag, keep, kind):
+        x = ops.f32(x).contiguous(); bias = ops.f32(bias).contiguous()
+        ops.require_cuda(x, bias, state)
+        rows, Cc = x.shape
+        out = torch.empty_like(x)
+        N.check(N.lib().md_bias_gelu_drop_ctr(ops._p(x), ops._p(bias), ops._p(state), int(tag), float(keep), None, 1.0 / float(keep), int(kind),
+                                              rows, Cc, ops._p(out), ops._stream()), "md_bias_gelu_drop_ctr")
+        ctx.save_for_backward(x, bias)
+        ctx.state, ctx.tag, ctx.keep, ctx.kind = state, int(tag), float(keep), int(kind)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, bias = ctx.saved_tensors
+        g = ops.f32(dout).contiguous()
+        rows, Cc = x.shape
+        dx = torch.empty_like(x)
+        N.check(N.lib().md_bias_gelu_drop_ctr(ops._p(x), ops._p(bias), ops._p(ctx.state), ctx.tag, ctx.keep, ops._p(g), 1.0 / ctx.keep, ctx.kind,
+                                              rows, Cc, ops._p(dx), ops._stream()), "md_bias_gelu_drop_ctr")
+        db = torch.empty(Cc, device=g.device)
+        ns = N.lib().md_channel_bias_bwd_scratch_floats(rows, Cc, 1)
+        scratch = torch.empty(ns, device=g.device) if ns else None
+        N.check(N.lib().md_channel_bias_bwd(ops._p(dx), rows, Cc, 1, ops._p(db), ops._p(scratch), ops._stream()), "md_channel_bias_bwd")
+        return dx, db, None, None, None, None
+
+
 def linear_bias_gelu_dropout(x2d, weight, bias, p: float, training: bool, kind: int = 0):
     """dropout(gelu(x @ weight^T + bias)): the MFMA Linear, then one fused elementwise pass (three separately when the width is not a
     multiple of 4 or the Linear has no bias)."""
@@ -888,6 +1015,9 @@ def linear_bias_gelu_dropout(x2d, weight, bias, p: float, training: bool, kind: 
     y = y.contiguous()
     if training and p > 0.0:
         keep = 1.0 - p
+        site = ops.dropout_site() if y.is_cuda else None
+        if site is not None:
+            return BiasGeluDropCtrFunction.apply(y, bias, site[0], site[1], keep, kind)
         return BiasGeluDropFunction.apply(y, bias, torch.empty_like(y).bernoulli_(keep), 1.0 / keep, kind)
     return BiasGeluDropFunction.apply(y, bias, None, 1.0, kind)
 
@@ -899,10 +1029,14 @@ def linear_wb(x2d, weight, bias):
 
 
 def dropout(x, p: float, training: bool):
-    """Inverted dropout with a mask from torch's device generator, applied by md_mask_scale."""
+    """Inverted dropout.  Inside a model's ``ops.counter_dropout`` scope: mask-free (md_dropout_ctr); otherwise a mask from torch's
+    device generator, applied by md_mask_scale."""
     if not training or p <= 0.0:
         return x
     keep = 1.0 - p
+    site = ops.dropout_site() if x.is_cuda else None
+    if site is not None:
+        return CtrDropoutFunction.apply(x, site[0], site[1], keep)
     return _MaskScale.apply(x, torch.empty_like(x).bernoulli_(keep), 1.0 / keep)
 
 

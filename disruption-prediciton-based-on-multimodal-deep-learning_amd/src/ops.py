@@ -161,6 +161,45 @@ class prepacked:
         return False
 
 
+# ----------------------------------------------------------------------------------------- mask-free dropout
+# nn.Dropout without a mask tensor (md_dropout_ctr / md_bias_gelu_drop_ctr): the keep / drop decisions are a pure function of
+# (a 128-bit key, call-site tag, element index).  ``counter_dropout(device, training)`` is entered by a model's forward: it draws this
+# forward's key -- two int64 words from torch's DEVICE generator, one tiny launch per forward -- and numbers the dropout call sites of
+# the forward in call order; the backward of THIS forward regenerates the same decisions from the same key tensor whatever runs in
+# between.  Because the key comes from torch's generator, ``torch.manual_seed`` governs the stream exactly as it governs nn.Dropout's,
+# and a step recorded into a HIP graph draws a new key on every replay (torch advances the generator's offset per replay).
+_drop_ctx = None    # inside counter_dropout(): (this forward's key tensor, [next tag])
+_CTR_DROPOUT_OFF = os.environ.get("MD_CTR_DROPOUT") == "0"      # A/B switch: masks from torch's generator again
+
+
+class counter_dropout:
+    def __init__(self, device, training: bool):
+        self.device = torch.device(device)
+        self.on = bool(training) and self.device.type == "cuda" and not _CTR_DROPOUT_OFF
+
+    def __enter__(self):
+        global _drop_ctx
+        self.outer = _drop_ctx
+        if not self.on or self.outer is not None:        # (a nested model shares the enclosing forward's stream of decisions)
+            return self
+        _drop_ctx = (torch.empty(2, dtype=torch.int64, device=self.device).random_(), [0])
+        return self
+
+    def __exit__(self, *exc):
+        global _drop_ctx
+        _drop_ctx = self.outer
+        return False
+
+
+def dropout_site():
+    """(key tensor, tag) of the next dropout call site of the forward in progress, or None outside counter_dropout()."""
+    if _drop_ctx is None:
+        return None
+    tag = _drop_ctx[1][0]
+    _drop_ctx[1][0] = tag + 1
+    return _drop_ctx[0], tag
+
+
 class own_packs:
     """Hide the packs of an enclosing ``prepacked`` scope: a branch whose launches are RECORDED (src/utils/graphed.py::GraphedBranch)
     must pack its operands itself, inside the recording -- the buffers of the enclosing scope are temporaries of one eager forward,

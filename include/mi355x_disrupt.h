@@ -320,6 +320,20 @@ size_t md_add_layernorm_bwd_scratch_floats(int64_t rows, int32_t D);
  * NULL when that is 0). */
 int md_add_layernorm_bwd(const float* dout, const float* gamma, const float* xhat, const float* rstd, const float* dres,
                          int64_t rows, int32_t D, float* dx, float* dgamma, float* dbeta, float* scratch, void* stream);
+/* One step of ViViT's pre-norm residual stream with the branch's tail folded in (src/models/ViViT.py:31-46,85-91,108-111: the branch
+ * ends in nn.Linear -> nn.Dropout, then x = branch(x) + x and the next PreNorm's LayerNorm): y = the Linear's raw product [rows][D],
+ * bias [D] (may be NULL), key / tag / keep = the dropout decisions of md_dropout_ctr (key NULL: no dropout),
+ *   sum_out = (y + bias) * decision / keep + stream_in,   out = LayerNorm(sum_out) * gamma + beta   (xhat, rstd kept for the backward).
+ * Backward: dstream = gradient of sum_out (LayerNorm's plus dres, what arrived through the stream); dbranch = dstream * decision /
+ * keep = gradient of y (its column sum is the bias gradient: md_channel_bias_bwd); dgamma, dbeta, scratch as md_add_layernorm_bwd.
+ * D % 4 == 0, D <= 256, 16-byte aligned tensors (md_branch_layernorm_supported). */
+int md_branch_layernorm_supported(int64_t rows, int32_t D);
+int md_branch_layernorm_fwd(const float* y, const float* bias, const int64_t* key, int32_t tag, float keep, const float* stream_in,
+                            const float* gamma, const float* beta, int64_t rows, int32_t D, float eps, float* out, float* xhat,
+                            float* rstd, float* sum_out, void* stream);
+int md_branch_layernorm_bwd(const float* dout, const float* gamma, const float* xhat, const float* rstd, const float* dres,
+                            const int64_t* key, int32_t tag, float keep, int64_t rows, int32_t D, float* dstream, float* dbranch,
+                            float* dgamma, float* dbeta, float* scratch, void* stream);
 /* batch_first = 0: qkv [S][B][3D], out [S][B][D] (nn.MultiheadAttention); 1: qkv [B][S][3D], out [B][S][D] (ViViT's Attention,
  * src/models/ViViT.py:69-88: 'b n (h d)' heads, scale d_head^-0.5, no mask).  S*16*4 bytes of LDS: S <= 937. */
 int md_attention_fwd(const float* qkv, const float* mask, const float* drop, int32_t S, int32_t B, int32_t D, int32_t H,
@@ -346,6 +360,15 @@ int md_gelu(const float* x, const float* dy, int32_t kind, int64_t n, float* out
  * md_channel_bias_fwd -> md_gelu -> md_mask_scale. */
 int md_bias_gelu_drop(const float* x, const float* bias, const float* mask, const float* dout, float scale, int32_t kind, int64_t rows,
                       int32_t C, float* out, void* stream);
+/* Mask-free inverted dropout (nn.Dropout in training mode: ViViT.py:31-46,85-91; the reference draws a mask from the framework's
+ * generator, whose stream is device- and version-specific anyway): element i is kept when a Philox4x32-10 word of
+ * (state = a 128-bit key, a device int64[2] the caller draws once per forward --, tag = call site, i) is below keep; out = x * scale where kept, 0 elsewhere.  The
+ * same (state, tag) regenerates the same decisions, so the backward pass is the same call on the gradient and no mask tensor is
+ * written or read (at cfg3 the FeedForward's mask alone was a 68 MB write and two 68 MB reads per layer and step).
+ * md_bias_gelu_drop_ctr: md_bias_gelu_drop with the decisions generated instead of read (dout != NULL: the backward). */
+int md_dropout_ctr(const float* x, const int64_t* state, int32_t tag, float keep, float scale, int64_t n, float* out, void* stream);
+int md_bias_gelu_drop_ctr(const float* x, const float* bias, const int64_t* state, int32_t tag, float keep, const float* dout,
+                          float scale, int32_t kind, int64_t rows, int32_t C, float* out, void* stream);
 /* Device-side tail of DatasetForVideo.get_video_data (src/dataset.py:124-144, without the cv2 augmentations): centre crop of
  * S x S (rows Hr/2 - S/2 .., columns Wr/2 - S/2 .., :241-246; S even), subtraction of the BGR means (:203-207, host array of 3)
  * and the (T,H,W,C) -> (C,T,H,W) transpose (:229-230) from uint8 frames [B][T][Hr][Wr][3].  layout 0: out [B][3][T][S][S];

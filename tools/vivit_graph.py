@@ -12,7 +12,7 @@ from src.utils.graphed import GraphedStep
 steps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 50
 torch.manual_seed(0)
 m = ViViT(image_size=224, patch_size=16, n_frames=21, n_classes=2, dim=128, depth=2, n_heads=4, pool="mean", in_channels=3, d_head=64,
-          dropout=0.1, embedd_dropout=0.1, scale_dim=8).cuda().train()
+          dropout=float(os.environ.get("VIVIT_DROPOUT", "0.1")), embedd_dropout=float(os.environ.get("VIVIT_DROPOUT", "0.1")), scale_dim=8).cuda().train()
 x = torch.randn(4, 3, 21, 224, 224, device="cuda"); y = torch.randint(0, 2, (4,), device="cuda")
 gs = GraphedStep(m, FocalLoss(gamma=2.0), [x], y)
 for _ in range(3):

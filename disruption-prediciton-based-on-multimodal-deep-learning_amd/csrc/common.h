@@ -105,6 +105,7 @@ struct WgradBeside { WgradBeside() { ++g_wgrad_beside; } ~WgradBeside() { --g_wg
 const WgradPlan* wgrad_lookup(const MdConvDesc* d, int xpitch = 0, int xc0 = 0, int dw_cin = 0);   // xpitch != 0: X = channel slice of a wider tensor
 size_t wgrad_patch_workspace_floats(const WgradPlan* p);
 bool wgrad_plan_xsplit_ok(const WgradPlan* p);
+bool wgrad_plan_second_form(const WgradPlan* p);      // this plan's launches go through k_wgrad2 (needed for a transposed result)
 int wgrad_patch_launch(const WgradPlan* p, const MdConvDesc* d, const float* src, const float* ps, const float* psh,
                        float slope, const float* dy, float* dw, float* slab, hipStream_t s, int ysplit = 0, int xsplit = 0);
 // second form of the weight gradient (conv_wgrad2.hip): two workgroups per CU, 64-pixel boxes, k-groups by input channel

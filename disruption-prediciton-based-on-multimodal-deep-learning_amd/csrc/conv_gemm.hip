@@ -638,6 +638,16 @@ static bool wide_linear_chunks(const MdConvDesc* d) {
   return !off && d->kt == 1 && d->kh == 1 && d->kw == 1 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 && d->ph == 0 && d->pw == 0 &&
          md_cpad(d->Cin) > 320;      // PMAXC of the patch kernels (exact-fp32 mode: wgrad_lookup declines, the gather kernel runs)
 }
+// ... or, when the OUTPUT side is narrow (FeedForward 1024 -> 128), in ONE launch with the operands' roles swapped: X' := dY (Cout
+// channels), dY' := X (Cin channels) is the weight gradient of a Cout -> Cin Linear, i.e. dW transposed; the slab reduction writes it
+// back transposed (conv_wgrad2.hip).  ViViT cfg3: 4 slab kernels + 4 reductions per FeedForward and step become 1 + 1.
+static const WgradPlan* wide_swapped_plan(const MdConvDesc* d, MdConvDesc* ds) {
+  static const int off = getenv("MD_WIDE_SWAP") && atoi(getenv("MD_WIDE_SWAP")) == 0;
+  if (off || md_cpad(d->Cout) > 320 || md_cpad(d->Cout) != d->Cout || md_cpad(d->Cin) != d->Cin) return nullptr;
+  *ds = *d; ds->Cin = d->Cout; ds->Cout = d->Cin;
+  const WgradPlan* wp = wgrad_lookup(ds, 0, 0, -1);
+  return (wp && wgrad_plan_second_form(wp)) ? wp : nullptr;
+}
 static const WgradPlan* wide_chunk_plan(const MdConvDesc* d, int c0) {
   MdConvDesc dc = *d;
   dc.Cin = d->Cin - c0 < WIDE_CHUNK ? d->Cin - c0 : WIDE_CHUNK;
@@ -673,7 +683,9 @@ extern "C" size_t md_conv_wgrad_workspace_floats(const MdConvDesc* d) {
   if (const WgradPlan* wp = wgrad_lookup(d)) return wgrad_patch_workspace_floats(wp);
   if (wide_linear_chunks(d)) {
     size_t need = 0;
-    for (int c0 = 0; c0 < d->Cin; c0 += WIDE_CHUNK) {
+    MdConvDesc ds;
+    if (const WgradPlan* wp = wide_swapped_plan(d, &ds)) need = wgrad_patch_workspace_floats(wp);     // (the slices' need is kept too:
+    for (int c0 = 0; c0 < d->Cin; c0 += WIDE_CHUNK) {                                                  //  the form is chosen per call)
       const WgradPlan* wp = wide_chunk_plan(d, c0);
       if (!wp) return 0;
       const size_t n = wgrad_patch_workspace_floats(wp);
@@ -692,6 +704,14 @@ extern "C" int md_conv_wgrad(const MdConvDesc* d, const MdActView* x, const floa
   if (const WgradPlan* wp = wgrad_lookup(d)) {
     if (!workspace) return MD_ERR_WORKSPACE;
     return wgrad_patch_launch(wp, d, x->data, x->scale, x->shift, x->slope, dy_raw, dw, workspace, (hipStream_t)stream);
+  }
+  if (wide_linear_chunks(d) && workspace && !x->scale) {
+    MdConvDesc ds;
+    if (const WgradPlan* wp = wide_swapped_plan(d, &ds)) {
+      MdActView dyv; dyv.data = dy_raw; dyv.scale = nullptr; dyv.shift = nullptr; dyv.slope = 1.f;
+      rc = wgrad_patch_launch(wp, &ds, dyv.data, nullptr, nullptr, 1.f, x->data, dw, workspace, (hipStream_t)stream);
+      if (rc != MD_ERR_UNSUPPORTED) return rc;
+    }
   }
   if (wide_linear_chunks(d) && workspace) {
     bool all = true;

@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
   }
 }
 
-struct WgradPlan { WGeom g; size_t lds; int nslices; bool w8; const Wgrad2Plan* v2; };
+struct WgradPlan { WGeom g; size_t lds; int nslices; bool w8; const Wgrad2Plan* v2; bool transposed = false; };
 
 // xpitch / xc0: X is the channel slice [xc0, xc0 + Cin) of a tensor with xpitch floats per pixel (0: X is the whole tensor);
 // dW then goes to columns [xc0, xc0 + Cin) of a (Cout, dw_cin, taps) tensor
@@ -725,11 +725,13 @@ const WgradPlan* wgrad_lookup(const MdConvDesc* d, int xpitch, int xc0, int dw_c
     ns = md_cdiv(g.nboxes, g.boxes_per_wg);
     wp = new WgradPlan(); wp->g = g; wp->lds = lds; wp->nslices = ns; wp->w8 = w8;
     wp->v2 = wgrad2_lookup(d, beside, xpitch, xc0, dw_cin);
+    wp->transposed = !xpitch && dw_cin < 0;
   }
   cache[key] = wp;
   return wp;
 }
 
+bool wgrad_plan_second_form(const WgradPlan* p) { return p->v2 != nullptr && !g_wgrad_first_form.load(); }
 bool wgrad_plan_xsplit_ok(const WgradPlan* p) { return !p->g.pack2 && p->g.xpitch == p->g.Cpi; }
 size_t wgrad_patch_workspace_floats(const WgradPlan* p) {
   const size_t a = (size_t)p->nslices * p->g.nkt * 16 * p->g.N16, b = p->v2 ? wgrad2_workspace_floats(p->v2) : 0;
@@ -750,6 +752,7 @@ int wgrad_patch_launch(const WgradPlan* p, const MdConvDesc* d, const float* src
                        float slope, const float* dy, float* dw, float* slab, hipStream_t s, int ysplit, int xsplit) {
   const WGeom& g = p->g;
   if (p->v2 && !ysplit && !xsplit && !g_wgrad_first_form.load()) return wgrad2_launch(p->v2, d, src, ps, psh, slope, dy, dw, slab, s);
+  if (p->transposed) return MD_ERR_UNSUPPORTED;          // only the second form writes the transposed result
   if (ysplit && (g.Cpo & 7)) return MD_ERR_UNSUPPORTED;
   if (xsplit && (g.pack2 || g.xpitch != g.Cpi || ps)) return MD_ERR_UNSUPPORTED;      // whole-tensor, already activated X only
   const int fmt = (ysplit ? 1 : 0) | (xsplit ? 2 : 0);

@@ -383,7 +383,10 @@ __device__ __forceinline__ void wgrad2_reduce_body(const float* __restrict__ sla
     const int nktg = taps * KTg;
     const int kg = kt / nktg; const int lt = kt - kg * nktg;
     const int tap = lt / KTg; const int c = ((kg * KTg) + (lt - tap * KTg)) * 16 + (krow & 15);
-    if (co < Cout && c < Cin) dw[((size_t)co * dw_cin + dw_c0 + c) * taps + tap] = s;
+    if (co < Cout && c < Cin) {
+      if (dw_cin < 0) dw[(size_t)c * Cout + co] = s;       // transposed output (role-swapped Linear, see wgrad2_build): taps == 1
+      else dw[((size_t)co * dw_cin + dw_c0 + c) * taps + tap] = s;
+    }
   }
 }
 
@@ -437,6 +440,13 @@ static bool wgrad2_build(const MdConvDesc* d_in, W2Geom* out, size_t* lds_bytes,
   {
     g.xpitch = xpitch ? xpitch : g.Cpi; g.xc_base = xpitch ? xc_base : 0;
     g.dw_cin = xpitch ? dw_cin : d->Cin; g.dw_c0 = xpitch ? xc_base : 0;
+    // dw_cin < 0 (whole tensors only): the result is written TRANSPOSED, dw[cin][cout] -- a Linear whose input is wider than the staged
+    // channel range (ViViT's FeedForward 1024 -> 128) is computed with the operands' roles swapped (X := dY with 128 channels, dY := X
+    // with 1024), which is the [1024][128] transpose of its weight gradient: one launch instead of four channel slices
+    if (!xpitch && dw_cin < 0) {
+      if (d->kt * d->kh * d->kw != 1) return false;
+      g.dw_cin = -1;
+    }
     const unsigned long long xb = (unsigned long long)d->N * g.Ti * g.Hi * g.Wi * g.xpitch * 4ull;
     const unsigned long long yb = (unsigned long long)d->N * g.To * g.Ho * g.Wo * g.Cpo * 4ull;
     if (xb >= 0x80000000ull || yb >= 0x80000000ull) return false;      // buffer addressing: 2 GiB per tensor

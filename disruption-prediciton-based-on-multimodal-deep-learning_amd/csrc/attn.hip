@@ -1054,43 +1054,95 @@ __global__ __launch_bounds__(256) void k_branch_ln_fwd(const float* __restrict__
   }
 }
 // dstream = rstd * (g - mean(g) - xhat * mean(g * xhat)) + dres,  g = dout * gamma   (gradient of the sum: what the residual stream
-// carries on); dbranch = dstream * keep-decision * scale (gradient of the Linear's raw product; the bias gradient is its column sum).
+// carries on); dbranch = dstream * keep-decision * scale (gradient of the Linear's raw product).  The three column sums the step needs
+// ride along: dgamma = sum_rows dout * xhat, dbeta = sum_rows dout, dbias = sum_rows dbranch -- every workgroup walks its row groups
+// (blockIdx.x, + gridDim.x, ...) in order, adds the 256 / L row lanes in a fixed order at the end and writes one partial row
+// [3][D]; k_colsum3_final adds the partial rows in a fixed tree.  (Separate passes before: k_ln_param_grad + k_ln_param_sum +
+// k_colsum_partial + k_colsum_final, each re-reading an 8.5 MB tensor.)
 template <int L>
 __global__ __launch_bounds__(256) void k_branch_ln_bwd(const float* __restrict__ dout, const float* __restrict__ gamma, const float* __restrict__ xhat,
                                                       const float* __restrict__ rstd, const float* __restrict__ dres, const int64_t* __restrict__ key,
                                                       int tag, float keep, int64_t rows, int D4, float* __restrict__ dstream,
-                                                      float* __restrict__ dbranch) {
+                                                      float* __restrict__ dbranch, float* __restrict__ partial) {
   constexpr int RPB = 256 / L;
-  const int c4 = threadIdx.x % L;
-  const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / L;
-  const bool act = row < rows && c4 < D4;
-  const int64_t i4 = act ? row * D4 + c4 : 0;
-  float g[4] = {0.f, 0.f, 0.f, 0.f}, xh[4] = {0.f, 0.f, 0.f, 0.f};
-  if (act) {
-    const float4 a = ((const float4*)dout)[i4], gm = ((const float4*)gamma)[c4], x = ((const float4*)xhat)[i4];
-    g[0] = a.x * gm.x; g[1] = a.y * gm.y; g[2] = a.z * gm.z; g[3] = a.w * gm.w;
-    xh[0] = x.x; xh[1] = x.y; xh[2] = x.z; xh[3] = x.w;
-  }
+  extern __shared__ float sred[];                        // [RPB][3][D4 * 4]
+  const int c4 = threadIdx.x % L, rl = threadIdx.x / L;
   const float D = (float)(D4 * 4);
-  const float m1 = lanes_sum<L>((g[0] + g[1]) + (g[2] + g[3])) / D;
-  const float m2 = lanes_sum<L>((g[0] * xh[0] + g[1] * xh[1]) + (g[2] * xh[2] + g[3] * xh[3])) / D;
-  if (!act) return;
-  const float rs = rstd[row];
-  float r[4] = {0.f, 0.f, 0.f, 0.f};
-  if (dres) { const float4 t = ((const float4*)dres)[i4]; r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w; }
-  float dx[4];
+  float4 gm = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c4 < D4) gm = ((const float4*)gamma)[c4];
+  float acc[3][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  MdDropKey dk; dk.k0 = dk.k1 = dk.step = 0;
+  if (key) dk = md_drop_key(key);
+  const float sc = key ? 1.f / keep : 1.f;
+  const int64_t ngroups = (rows + RPB - 1) / RPB;
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t row = grp * RPB + rl;
+    const bool act = row < rows && c4 < D4;
+    const int64_t i4 = act ? row * D4 + c4 : 0;
+    float a[4] = {0.f, 0.f, 0.f, 0.f}, g[4] = {0.f, 0.f, 0.f, 0.f}, xh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (act) {
+      const float4 t = ((const float4*)dout)[i4], x = ((const float4*)xhat)[i4];
+      a[0] = t.x; a[1] = t.y; a[2] = t.z; a[3] = t.w;
+      g[0] = t.x * gm.x; g[1] = t.y * gm.y; g[2] = t.z * gm.z; g[3] = t.w * gm.w;
+      xh[0] = x.x; xh[1] = x.y; xh[2] = x.z; xh[3] = x.w;
+    }
+    const float m1 = lanes_sum<L>((g[0] + g[1]) + (g[2] + g[3])) / D;
+    const float m2 = lanes_sum<L>((g[0] * xh[0] + g[1] * xh[1]) + (g[2] * xh[2] + g[3] * xh[3])) / D;
+    if (!act) continue;
+    const float rs = rstd[row];
+    float r[4] = {0.f, 0.f, 0.f, 0.f};
+    if (dres) { const float4 t = ((const float4*)dres)[i4]; r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w; }
+    float dx[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) dx[e] = rs * (g[e] - m1 - xh[e] * m2) + r[e];
-  ((float4*)dstream)[i4] = make_float4(dx[0], dx[1], dx[2], dx[3]);
-  if (key) {
-    float m[4];
-    md_drop_keep4(md_drop_key(key), tag, i4, keep, m);
-    const float sc = 1.f / keep;
+    for (int e = 0; e < 4; ++e) dx[e] = rs * (g[e] - m1 - xh[e] * m2) + r[e];
+    ((float4*)dstream)[i4] = make_float4(dx[0], dx[1], dx[2], dx[3]);
+    if (key) {
+      float m[4];
+      md_drop_keep4(dk, tag, i4, keep, m);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) dx[e] = dx[e] * m[e] * sc;
+      for (int e = 0; e < 4; ++e) dx[e] = dx[e] * m[e] * sc;
+    }
+    ((float4*)dbranch)[i4] = make_float4(dx[0], dx[1], dx[2], dx[3]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { acc[0][e] = fmaf(a[e], xh[e], acc[0][e]); acc[1][e] += a[e]; acc[2][e] += dx[e]; }
   }
-  ((float4*)dbranch)[i4] = make_float4(dx[0], dx[1], dx[2], dx[3]);
+  // the row lanes of this workgroup, in order
+  const int Dw = D4 * 4;
+  if (c4 < D4) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sred[(rl * 3 + q) * Dw + c4 * 4 + e] = acc[q][e];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * Dw; i += 256) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < RPB; ++k) t += sred[k * 3 * Dw + i];
+    partial[(size_t)blockIdx.x * 3 * Dw + i] = t;
+  }
 }
+// out[q][i] = sum over partial rows k of partial[k][q][i], q = 0..2 (dgamma, dbeta, dbias): 16 features x 16 row lanes per workgroup,
+// lane l adds rows l, l + 16, ... in order, then the 16 lanes in order
+__global__ __launch_bounds__(256) void k_colsum3_final(const float* __restrict__ partial, int nrows, int D, float* __restrict__ o0,
+                                                      float* __restrict__ o1, float* __restrict__ o2) {
+  __shared__ float red[16][16];
+  const int c = threadIdx.x & 15, l = threadIdx.x >> 4, i = blockIdx.x * 16 + c, q = blockIdx.y;
+  float* out = q == 0 ? o0 : q == 1 ? o1 : o2;
+  if (!out) return;
+  float t = 0.f;
+  if (i < D)
+    for (int k = l; k < nrows; k += 16) t += partial[((size_t)k * 3 + q) * D + i];
+  red[l][c] = t;
+  __syncthreads();
+  if (l == 0 && i < D) {
+    float sg = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sg += red[k][c];
+    out[i] = sg;
+  }
+}
+#define BLN_PARTIAL_ROWS 256
 extern "C" int md_branch_layernorm_supported(int64_t rows, int32_t D) { return rows > 0 && D > 0 && (D & 3) == 0 && D <= 256 ? 1 : 0; }
 extern "C" int md_branch_layernorm_fwd(const float* y, const float* bias, const int64_t* key, int32_t tag, float keep, const float* stream_in,
                                        const float* gamma, const float* beta, int64_t rows, int32_t D, float eps, float* out, float* xhat,
@@ -1108,31 +1160,30 @@ extern "C" int md_branch_layernorm_fwd(const float* y, const float* bias, const 
   MD_CHECK_LAUNCH();
   return MD_OK;
 }
+extern "C" size_t md_branch_layernorm_bwd_scratch_floats(int64_t rows, int32_t D) {
+  return md_branch_layernorm_supported(rows, D) ? (size_t)BLN_PARTIAL_ROWS * 3 * (size_t)D : 0;
+}
 extern "C" int md_branch_layernorm_bwd(const float* dout, const float* gamma, const float* xhat, const float* rstd, const float* dres,
                                        const int64_t* key, int32_t tag, float keep, int64_t rows, int32_t D, float* dstream, float* dbranch,
-                                       float* dgamma, float* dbeta, float* scratch, void* stream) {
-  if (!dout || !gamma || !xhat || !rstd || !dstream || !dbranch || !dgamma || !dbeta) return MD_ERR_NULL;
+                                       float* dgamma, float* dbeta, float* dbias, float* scratch, void* stream) {
+  if (!dout || !gamma || !xhat || !rstd || !dstream || !dbranch || !dgamma || !dbeta || !scratch) return MD_ERR_NULL;
   if (!md_branch_layernorm_supported(rows, D) || (key && !(keep > 0.f && keep <= 1.f))) return MD_ERR_BAD_SHAPE;
   if ((((uintptr_t)dout | (uintptr_t)gamma | (uintptr_t)xhat | (uintptr_t)dres | (uintptr_t)dstream | (uintptr_t)dbranch) & 15) != 0) return MD_ERR_BAD_SHAPE;
-  const bool chunked = md_add_layernorm_bwd_scratch_floats(rows, D) != 0;
-  if (chunked && !scratch) return MD_ERR_WORKSPACE;
   const int D4 = D / 4;
   hipStream_t s = (hipStream_t)stream;
-#define BLN_BWD(L_) MD_KLAUNCH(k_branch_ln_bwd<L_>, dim3((unsigned)((rows + 256 / L_ - 1) / (256 / L_))), dim3(256), 0, s, dout, gamma, xhat, rstd, dres, \
-                               key, tag, keep, rows, D4, dstream, dbranch)
+  int nwg = 0;
+#define BLN_BWD(L_)                                                                                                                   \
+  do {                                                                                                                                \
+    const int64_t groups = (rows + 256 / L_ - 1) / (256 / L_);                                                                        \
+    nwg = (int)(groups < BLN_PARTIAL_ROWS ? groups : BLN_PARTIAL_ROWS);                                                               \
+    MD_KLAUNCH(k_branch_ln_bwd<L_>, dim3((unsigned)nwg), dim3(256), (size_t)(256 / L_) * 3 * D * 4, s, dout, gamma, xhat, rstd, dres, key, tag, keep, \
+               rows, D4, dstream, dbranch, scratch);                                                                                  \
+  } while (0)
   if (D4 <= 16) BLN_BWD(16); else if (D4 <= 32) BLN_BWD(32); else BLN_BWD(64);
 #undef BLN_BWD
   MD_CHECK_LAUNCH();
-  if (!chunked) {
-    MD_KLAUNCH(k_ln_param_grad, dim3(md_cdiv(D, 64), 1), dim3(256), 0, s, dout, xhat, (int)rows, D, dgamma, dbeta);
-    MD_CHECK_LAUNCH();
-  } else {
-    float* pg = scratch; float* pb = scratch + (size_t)LN_CHUNKS * D;
-    MD_KLAUNCH(k_ln_param_grad, dim3(md_cdiv(D, 64), LN_CHUNKS), dim3(256), 0, s, dout, xhat, (int)rows, D, pg, pb);
-    MD_CHECK_LAUNCH();
-    MD_KLAUNCH(k_ln_param_sum, dim3(md_cdiv(D, 16)), dim3(256), 0, s, (const float*)pg, (const float*)pb, LN_CHUNKS, D, dgamma, dbeta);
-    MD_CHECK_LAUNCH();
-  }
+  MD_KLAUNCH(k_colsum3_final, dim3(md_cdiv(D, 16), 3), dim3(256), 0, s, (const float*)scratch, nwg, D, dgamma, dbeta, dbias);
+  MD_CHECK_LAUNCH();
   return MD_OK;
 }
 

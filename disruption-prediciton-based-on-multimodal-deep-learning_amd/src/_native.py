@@ -161,7 +161,8 @@ SIGNATURES = {
     "md_dropout_ctr": (C.c_int, [_P, _P, _I32, _F, _F, _I64, _P, _P]),
     "md_branch_layernorm_supported": (C.c_int, [_I64, _I32]),
     "md_branch_layernorm_fwd": (C.c_int, [_P, _P, _P, _I32, _F, _P, _P, _P, _I64, _I32, _F, _P, _P, _P, _P, _P]),
-    "md_branch_layernorm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _F, _I64, _I32, _P, _P, _P, _P, _P, _P]),
+    "md_branch_layernorm_bwd_scratch_floats": (_SZ, [_I64, _I32]),
+    "md_branch_layernorm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _F, _I64, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "md_bias_gelu_drop_ctr": (C.c_int, [_P, _P, _P, _I32, _F, _P, _F, _I32, _I64, _I32, _P, _P]),
     "md_lstm_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P]),
     "md_lstm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P]),

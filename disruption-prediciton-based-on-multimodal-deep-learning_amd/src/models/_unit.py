@@ -766,11 +766,12 @@ class BranchResidualLayerNormFunction(torch.autograd.Function):
             dres = None if ds is None else ops.f32(ds).contiguous()
             dsum = torch.empty_like(g); dy = torch.empty_like(g)
             dgamma = torch.empty(D, device=dev); dbeta = torch.empty(D, device=dev)
-            ns = N.lib().md_add_layernorm_bwd_scratch_floats(rows, D)
-            scratch = torch.empty(ns, device=dev) if ns else None
+            db = torch.empty(D, device=dev) if ctx.has_bias else None
+            scratch = torch.empty(N.lib().md_branch_layernorm_bwd_scratch_floats(rows, D), device=dev)
             N.check(N.lib().md_branch_layernorm_bwd(ops._p(g), ops._p(gamma.contiguous()), ops._p(xhat), ops._p(rstd), ops._p(dres), ops._p(ctx.key),
                                                     ctx.tag, ctx.keep, rows, D, ops._p(dsum), ops._p(dy), ops._p(dgamma), ops._p(dbeta),
-                                                    ops._p(scratch), ops._stream()), "md_branch_layernorm_bwd")
+                                                    ops._p(db), ops._p(scratch), ops._stream()), "md_branch_layernorm_bwd")
+            return dy, db, dsum, dgamma, dbeta, None, None, None
         db = None
         if ctx.has_bias:
             db = torch.empty(D, device=dev)

@@ -325,15 +325,17 @@ int md_add_layernorm_bwd(const float* dout, const float* gamma, const float* xha
  * bias [D] (may be NULL), key / tag / keep = the dropout decisions of md_dropout_ctr (key NULL: no dropout),
  *   sum_out = (y + bias) * decision / keep + stream_in,   out = LayerNorm(sum_out) * gamma + beta   (xhat, rstd kept for the backward).
  * Backward: dstream = gradient of sum_out (LayerNorm's plus dres, what arrived through the stream); dbranch = dstream * decision /
- * keep = gradient of y (its column sum is the bias gradient: md_channel_bias_bwd); dgamma, dbeta, scratch as md_add_layernorm_bwd.
+ * keep = gradient of y; dgamma, dbeta and dbias (the column sum of dbranch) come out of the same pass + one small fixed-order
+ * reduction; scratch: md_branch_layernorm_bwd_scratch_floats.
  * D % 4 == 0, D <= 256, 16-byte aligned tensors (md_branch_layernorm_supported). */
 int md_branch_layernorm_supported(int64_t rows, int32_t D);
 int md_branch_layernorm_fwd(const float* y, const float* bias, const int64_t* key, int32_t tag, float keep, const float* stream_in,
                             const float* gamma, const float* beta, int64_t rows, int32_t D, float eps, float* out, float* xhat,
                             float* rstd, float* sum_out, void* stream);
+size_t md_branch_layernorm_bwd_scratch_floats(int64_t rows, int32_t D);
 int md_branch_layernorm_bwd(const float* dout, const float* gamma, const float* xhat, const float* rstd, const float* dres,
                             const int64_t* key, int32_t tag, float keep, int64_t rows, int32_t D, float* dstream, float* dbranch,
-                            float* dgamma, float* dbeta, float* scratch, void* stream);
+                            float* dgamma, float* dbeta, float* dbias /* may be NULL */, float* scratch, void* stream);
 /* batch_first = 0: qkv [S][B][3D], out [S][B][D] (nn.MultiheadAttention); 1: qkv [B][S][3D], out [B][S][D] (ViViT's Attention,
  * src/models/ViViT.py:69-88: 'b n (h d)' heads, scale d_head^-0.5, no mask).  S*16*4 bytes of LDS: S <= 937. */
 int md_attention_fwd(const float* qkv, const float* mask, const float* drop, int32_t S, int32_t B, int32_t D, int32_t H,

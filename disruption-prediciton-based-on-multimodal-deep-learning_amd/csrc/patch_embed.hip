@@ -11,6 +11,7 @@
 // the gradient).  The clip is addressed by strides (sb, st, sc floats; rows contiguous), so both (b, t, c, H, W) and the
 // permuted view of a (b, c, t, H, W) clip are read in place.
 #include "patch_common.h"
+#include <cstdlib>
 #include "../../include/mi355x_disrupt.h"
 
 #define PE_M 128          // token rows per workgroup
@@ -266,7 +267,8 @@ extern "C" int md_patch_embed_fwd(const float* x, int32_t B, int32_t T, int32_t 
   if (md_get_exact_fp32()) return MD_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   int npb = 128;
-  while (md_cdiv(g.M, PE_M) * md_cdiv(g.N16, npb) < 512 && npb > 32) npb >>= 1;
+  static const int fill = getenv("MD_PE_FILL") ? atoi(getenv("MD_PE_FILL")) : 512;
+  while (md_cdiv(g.M, PE_M) * md_cdiv(g.N16, npb) < fill && npb > 32) npb >>= 1;
   MD_KLAUNCH(k_patch_embed_fwd, dim3(md_cdiv(g.M, PE_M), md_cdiv(g.N16, npb)), dim3(256), 0, s, g, x, w_perm, bias, pos, out, npb);
   MD_CHECK_LAUNCH();
   MD_KLAUNCH(k_patch_embed_token, dim3(md_cdiv(B * T * dim, 256)), dim3(256), 0, s, g, token, pos, out);

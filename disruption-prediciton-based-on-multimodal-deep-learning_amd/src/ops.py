@@ -107,6 +107,7 @@ def from_channels_last(x: torch.Tensor, channels: int) -> torch.Tensor:
 _pack_stream = [None]   # the stream the packs of the active prepacked() scope were made on
 _pack_memo = {}        # id(weight) -> (weak reference to the weight, descriptor fields, want_dgrad)
 _pack_ready = None     # inside prepacked(): id(weight) -> (descriptor fields, wf, wd)
+_BN_FUSED_FIN_ROWS = int(os.environ.get("MD_BN_FUSED_FIN_ROWS", "0"))   # partial rows up to which bn_backward fuses the finalize
 _PREPACK_OFF = os.environ.get("MD_PREPACK") == "0"      # A/B switch: every unit packs its own operands again
 
 
@@ -387,8 +388,8 @@ def residual_fwd(skip: N.MdActView, main: N.MdActView, alpha: float, like: torch
 
 
 def bn_backward(dA: torch.Tensor, main: N.MdActView, st: torch.Tensor, Cc: int, skip: Optional[N.MdActView] = None,
-                alpha: float = 1.0, fused_finalize: bool = False):
-    """Returns (d_raw, dS or None, dgamma, dbeta)."""
+                alpha: float = 1.0, fused_finalize: Optional[bool] = None):
+    """Returns (d_raw, dS or None, dgamma, dbeta).  ``fused_finalize`` None: decided by the number of partial rows (see below)."""
     require_cuda(dA, st)
     L = N.lib()
     rows = dA.numel() // dA.shape[-1]
@@ -402,9 +403,12 @@ def bn_backward(dA: torch.Tensor, main: N.MdActView, st: torch.Tensor, Cc: int, 
     dbeta = torch.empty(Cc, device=dA.device, dtype=torch.float32)
     d_raw = torch.empty_like(dA)
     dS = torch.empty_like(dA) if skip is not None else None
+    if fused_finalize is None:
+        fused_finalize = nb <= _BN_FUSED_FIN_ROWS
     if fused_finalize:
-        # the apply pass sums the partial rows itself: one launch instead of finalize + apply (measured slower in the R(2+1)D
-        # step -- every workgroup of the apply pass repeats the sum -- so it is not the default)
+        # the apply pass sums the partial rows itself: one launch instead of finalize + apply.  Every workgroup of the apply pass
+        # repeats the sum, so it pays only where the partial buffer is short (the small tensors of the composable models: one
+        # dependent launch less per unit); measured slower on the R(2+1)D step's big tensors (profiles/r03_bn_fused_finalize.txt)
         N.check(L.md_bn_bwd_apply_fused(_p(dA), 0, C.byref(main), sk, float(alpha), _p(st[0]), _p(st[1]), _p(part), nb, rows,
                                         _p(dgamma), _p(dbeta), rows, Cc, _p(d_raw), _p(dS), _stream()), "md_bn_bwd_apply_fused")
         return d_raw, dS, dgamma, dbeta

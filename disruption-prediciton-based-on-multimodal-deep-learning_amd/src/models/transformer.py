@@ -93,6 +93,11 @@ class TransformerEncoder(nn.Module):
         return conv1d_bn_leaky(y, c2, bn, 0.0, self.training)
 
     def forward(self, x: torch.Tensor):
+        from .. import ops
+        with ops.counter_dropout(x.device, self.training):      # the layers' nn.Dropout without mask tensors (md_dropout_ctr)
+            return self._forward(x)
+
+    def _forward(self, x: torch.Tensor):
         x = self.noise(x)
         x = self._filter(x.permute(0, 2, 1)).permute(2, 0, 1).contiguous()          # (T, B, D)
         # the reference rebuilds the (constant) causal mask on the CPU and uploads it every forward (:98-99), which puts a

@@ -970,6 +970,7 @@ int patch_launch(const PatchPlan* p, const float* src, const float* ps, const fl
 #define LB_M 128
 #define LB_K 32
 #define LB_P 80
+#define LB_PD 3           // stages of both operands in flight (registers)
 // W8: eight waves on the same 128-row tile (two per SIMD, so one wave's staging arithmetic overlaps the other's MFMAs): waves 0-3 take
 // the first half of the column tiles, waves 4-7 the second; a thread then stages 8 floats per operand instead of 16.
 template <bool F16, bool W8>
@@ -983,15 +984,24 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void k_linear_split(const float* __
   const int ncols = min(npb, N16 - n0), nt = ncols >> 4;
   const int r = W8 ? t >> 2 : t >> 1, h = W8 ? t & 3 : t & 1;      // staging: row r, floats 4 NQ h .. 4 NQ (h + 1) - 1 of the stage
   const bool arow = m0 + r < M, brow = r < ncols;
-  const float* ap = A + (size_t)(m0 + r) * K + h * 4 * NQ;
-  const float* bp = W + (size_t)(n0 + r) * Kp + h * 4 * NQ;
-  float4 ra[NQ], rb[NQ];
-  auto load = [&](int kb) {
+  // raw buffer loads: a row outside the tile gets the out-of-range offset (reads as 0), so the prefetch is a straight run of loads with
+  // no branches in it (host side: both operands < 2 GiB)
+  const __amdgpu_buffer_rsrc_t ars = make_rsrc(A, (unsigned)((size_t)M * K * 4)), brs = make_rsrc(W, (unsigned)((size_t)N16 * Kp * 4));
+  const unsigned aoff = arow ? (unsigned)(((size_t)(m0 + r) * K + h * 4 * NQ) * 4) : MD_OOB;
+  const unsigned boff = brow ? (unsigned)(((size_t)(n0 + r) * Kp + h * 4 * NQ) * 4) : MD_OOB;
+  // LB_PD stages of both operands are in flight (registers).  A stage is 12-24 MFMAs per wave, far less than one memory latency, and with
+  // a single stage ahead every one of the K / 32 stages waited for its loads (FeedForward 1024 -> 128 at 16.5 k rows: 51 us for a 68 MB
+  // read).  The loads are branch-free raw buffer loads and the loop body is LB_PD whole stages, so the compiler waits once per body
+  // (vmcnt(0) at the loop head) for loads issued up to LB_PD stages earlier.  Measured (tools/r03_linear_abl.py): 3 stages 47.7 / 48.8 us
+  // for the two 1024-wide Linears (1: 51.3 / 50.8); 4 stages cost the second workgroup per CU (142 VGPRs: 61.9 / 63.7), and so did 64-k
+  // stages with their 73 KB of LDS (66.9 / 64.5): two resident workgroups matter more than either.
+  float4 ra[LB_PD][NQ], rb[LB_PD][NQ];
+  auto load = [&](int kb, float4 (&va)[NQ], float4 (&vb)[NQ]) {
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
       const int k = kb * LB_K + h * 4 * NQ + i * 4;
-      ra[i] = (arow && k < K) ? *(const float4*)(ap + kb * LB_K + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-      rb[i] = brow ? *(const float4*)(bp + kb * LB_K + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      va[i] = buf_load4(ars, k < K ? aoff + (unsigned)(kb * LB_K + i * 4) * 4u : MD_OOB);      // (K % 4 == 0: a float4 is inside the row or past it)
+      vb[i] = buf_load4(brs, (boff == MD_OOB || kb * LB_K >= Kp) ? MD_OOB : boff + (unsigned)(kb * LB_K + i * 4) * 4u);
     }
   };
   auto store = [&](const float4 (&v)[NQ], char* hi, char* lo) {
@@ -1013,29 +1023,38 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void k_linear_split(const float* __
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int nstages = Kp / LB_K;
-  load(0);
-  for (int kb = 0; kb < nstages; ++kb) {
-    __syncthreads();
-    store(ra, aH, aL);
-    store(rb, bH, bL);
-    __syncthreads();
-    if (kb + 1 < nstages) load(kb + 1);
-    uint4 ah[2], al[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      ah[i] = *(const uint4*)(aH + (wave * 32 + i * 16 + li) * LB_P + lg * 16);
-      al[i] = *(const uint4*)(aL + (wave * 32 + i * 16 + li) * LB_P + lg * 16);
-    }
+  for (int u = 0; u < LB_PD; ++u) load(u, ra[u], rb[u]);       // (unconditional: past the last stage the offsets are out of range)
+  // (the body is LB_PD whole stages with no exit in between -- stages past the last one multiply zeros -- so that the load / wait
+  // pattern is the same on every path into the loop header and the waits cover one stage, not everything in flight)
+  for (int kb0 = 0; kb0 < nstages; kb0 += LB_PD) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      if (j < jn) {
-        const uint4 bh = *(const uint4*)(bH + ((jlo + j) * 16 + li) * LB_P + lg * 16);
-        const uint4 bl = *(const uint4*)(bL + ((jlo + j) * 16 + li) * LB_P + lg * 16);
+    for (int u = 0; u < LB_PD; ++u) {
+      const int kb = kb0 + u;
+      {
+        __syncthreads();
+        store(ra[u], aH, aL);
+        store(rb[u], bH, bL);
+        __syncthreads();
+        load(kb + LB_PD, ra[u], rb[u]);        // always issued (out of range past the end): the wait counts then cover exactly one stage
+        uint4 ah[2], al[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          acc[i][j] = mma<F16>(ah[i], bh, acc[i][j]);
-          acc[i][j] = mma<F16>(ah[i], bl, acc[i][j]);
-          acc[i][j] = mma<F16>(al[i], bh, acc[i][j]);
+          ah[i] = *(const uint4*)(aH + (wave * 32 + i * 16 + li) * LB_P + lg * 16);
+          al[i] = *(const uint4*)(aL + (wave * 32 + i * 16 + li) * LB_P + lg * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if (j < jn) {
+            const uint4 bh = *(const uint4*)(bH + ((jlo + j) * 16 + li) * LB_P + lg * 16);
+            const uint4 bl = *(const uint4*)(bL + ((jlo + j) * 16 + li) * LB_P + lg * 16);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              acc[i][j] = mma<F16>(ah[i], bh, acc[i][j]);
+              acc[i][j] = mma<F16>(ah[i], bl, acc[i][j]);
+              acc[i][j] = mma<F16>(al[i], bh, acc[i][j]);
+            }
+          }
         }
       }
     }
@@ -1069,6 +1088,7 @@ int linear_split_launch(int f16, const float* A, int M, int K, const float* W, i
   if (g_exact_fp32.load()) return MD_ERR_UNSUPPORTED;
   static const int off = getenv("MD_LINEAR_SPLIT") && atoi(getenv("MD_LINEAR_SPLIT")) == 0;
   if (off || (K & 3) || (Kp % LB_K) || (N16 & 15)) return MD_ERR_UNSUPPORTED;
+  if ((size_t)M * K * 4 >= 0x80000000ull || (size_t)N16 * Kp * 4 >= 0x80000000ull) return MD_ERR_UNSUPPORTED;      // buffer addressing
   int npb = 128;
   static const int fill = getenv("MD_LINEAR_FILL") ? atoi(getenv("MD_LINEAR_FILL")) : 256;   // ViViT cfg3 captured step: 512 -> 4.62 ms, 256 -> 4.38, 130 / 64 -> 4.43
   while (md_cdiv(M, LB_M) * md_cdiv(N16, npb) < fill && npb > 32) npb >>= 1;

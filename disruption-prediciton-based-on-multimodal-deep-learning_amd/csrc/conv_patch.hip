@@ -1090,7 +1090,10 @@ int linear_split_launch(int f16, const float* A, int M, int K, const float* W, i
   if (off || (K & 3) || (Kp % LB_K) || (N16 & 15)) return MD_ERR_UNSUPPORTED;
   if ((size_t)M * K * 4 >= 0x80000000ull || (size_t)N16 * Kp * 4 >= 0x80000000ull) return MD_ERR_UNSUPPORTED;      // buffer addressing
   int npb = 128;
-  static const int fill = getenv("MD_LINEAR_FILL") ? atoi(getenv("MD_LINEAR_FILL")) : 256;   // ViViT cfg3 captured step: 512 -> 4.62 ms, 256 -> 4.38, 130 / 64 -> 4.43
+  // column split until this many workgroups exist.  Round 2 (one stage in flight): 512 -> 4.62 ms, 256 -> 4.38, 130 / 64 -> 4.43 for the
+  // ViViT cfg3 captured step; round 3 (three stages in flight): 130 -> 2.541, 256 -> 2.579, 512 -> 2.675 -- re-reading the A rows per
+  // column block now costs more than the idle half of the chip
+  static const int fill = getenv("MD_LINEAR_FILL") ? atoi(getenv("MD_LINEAR_FILL")) : 128;
   while (md_cdiv(M, LB_M) * md_cdiv(N16, npb) < fill && npb > 32) npb >>= 1;
   const dim3 grid(md_cdiv(M, LB_M), md_cdiv(N16, npb));
   static const int w8 = getenv("MD_LINEAR_W8") ? atoi(getenv("MD_LINEAR_W8")) : 1;

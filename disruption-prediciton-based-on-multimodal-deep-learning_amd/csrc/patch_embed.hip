@@ -16,6 +16,7 @@
 
 #define PE_M 128          // token rows per workgroup
 #define PE_K 32           // k' per stage
+#define PE_PD 3           // stages of both operands in flight (registers)
 #define PE_P 80           // LDS row pitch of a 32-half stage (bytes): 64 + pad, (80/16) % 4 == 1 -> conflict free with lg * 16
 
 struct PEGeom {
@@ -52,14 +53,18 @@ __global__ __launch_bounds__(256) void k_patch_embed_fwd(PEGeom g, const float* 
   const bool arow = m0 + r < g.M, brow = r < ncols && n0 + r < g.dim;
   const long long abase = arow ? pe_row_base(g, m0 + r) : 0;
   const float* bp = Wp + (size_t)(n0 + r) * g.K + h * 16;
-  float4 ra[4], rb[4];
-  auto load = [&](int kb) {
+  // PE_PD stages of both operands in flight, every load issued unconditionally (a position outside the operand reads a valid dummy
+  // address and is zeroed afterwards) and the loop body PE_PD whole stages: see k_linear_split (conv_patch.hip)
+  float4 ra[PE_PD][4], rb[PE_PD][4];
+  auto load = [&](int kb, float4 (&va)[4], float4 (&vb)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int k = kb * PE_K + h * 16 + i * 4;
       const bool kin = k < g.K;
-      ra[i] = (arow && kin) ? *(const float4*)(x + abase + pe_k_off(g, k)) : make_float4(0.f, 0.f, 0.f, 0.f);
-      rb[i] = (brow && kin) ? *(const float4*)(bp + kb * PE_K + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 a = *(const float4*)((arow && kin) ? x + abase + pe_k_off(g, k) : x);
+      const float4 b = *(const float4*)((brow && kin) ? bp + kb * PE_K + i * 4 : Wp);
+      va[i] = (arow && kin) ? a : make_float4(0.f, 0.f, 0.f, 0.f);
+      vb[i] = (brow && kin) ? b : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto store = [&](const float4 (&v)[4], char* hi, char* lo) {
@@ -78,13 +83,17 @@ __global__ __launch_bounds__(256) void k_patch_embed_fwd(PEGeom g, const float* 
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int nstages = g.Kp / PE_K;
-  load(0);
-  for (int kb = 0; kb < nstages; ++kb) {
+#pragma unroll
+  for (int u = 0; u < PE_PD; ++u) load(u, ra[u], rb[u]);
+  for (int kb0 = 0; kb0 < nstages; kb0 += PE_PD) {
+#pragma unroll
+  for (int u = 0; u < PE_PD; ++u) {
+    const int kb = kb0 + u;
     __syncthreads();
-    store(ra, aH, aL);
-    store(rb, bH, bL);
+    store(ra[u], aH, aL);
+    store(rb[u], bH, bL);
     __syncthreads();
-    if (kb + 1 < nstages) load(kb + 1);
+    load(kb + PE_PD, ra[u], rb[u]);
     uint4 ah[2], al[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -104,6 +113,7 @@ __global__ __launch_bounds__(256) void k_patch_embed_fwd(PEGeom g, const float* 
         }
       }
     }
+  }
   }
   // epilogue: + Linear bias + positional row; token j of frame bt -> row bt (n + 1) + 1 + j
 #pragma unroll
@@ -169,43 +179,73 @@ __global__ __launch_bounds__(256) void k_patch_embed_wgrad(PEGeom g, const float
 #pragma unroll
   for (int j = 0; j < NT8; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int NC = g.N16 / 8;                         // 8-column chunks of a g_out row
-  for (int box = box_beg; box < box_end; ++box) {
+  // The loads of box n + 1 (both operands, registers) are in flight during the matrix phase of box n; the g_out rows are read as two
+  // 16-byte loads per item when the width allows (dim % 8 == 0), element by element otherwise.
+  constexpr int NYI = NT8;                          // g_out items (8 floats) per thread: 128 rows x 2 NT8 chunks / 256 threads
+  const bool yvec = (g.dim & 7) == 0 && NC == 2 * NT8;
+  float4 ra[4][2], ry[NYI][2];
+  auto load_box = [&](int box) {
     const int m0 = box * PE_M;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int item = u * 256 + t;
+      const int r = item >> 3, c8 = item & 7;
+      const int k = k0 + c8 * 8;
+      const bool ok = m0 + r < g.M && k < g.K;
+      const float* s = ok ? x + pe_row_base(g, m0 + r) + pe_k_off(g, k) : x;      // p >= 8: 8 consecutive k' share an image row
+      const float4 a = *(const float4*)s, b = *(const float4*)(s + 4);
+      ra[u][0] = ok ? a : make_float4(0.f, 0.f, 0.f, 0.f); ra[u][1] = ok ? b : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < NYI; ++u) {
+      const int item = u * 256 + t;
+      const int r = item / NC, c = item - r * NC;
+      const int m = m0 + r;
+      const bool ok = item < PE_M * NC && m < g.M;
+      const int bt = ok ? m / g.n : 0, j = ok ? m - bt * g.n : 0;
+      const float* s = ok ? gout + ((size_t)bt * (g.n + 1) + 1 + j) * g.dim + c * 8 : gout;
+      if (yvec) {
+        const float4 a = *(const float4*)s, b = *(const float4*)(s + 4);
+        ry[u][0] = ok ? a : make_float4(0.f, 0.f, 0.f, 0.f); ry[u][1] = ok ? b : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) if (c * 8 + e < g.dim) v[e] = s[e];
+        }
+        ry[u][0] = make_float4(v[0], v[1], v[2], v[3]); ry[u][1] = make_float4(v[4], v[5], v[6], v[7]);
+      }
+    }
+  };
+  if (box_beg < box_end) load_box(box_beg);
+  for (int box = box_beg; box < box_end; ++box) {
     __syncthreads();                                // previous box consumed
     // ---- A: 128 rows x 64 k' = 8 chunks of 8 floats per row: 1024 items, 4 per thread
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int item = u * 256 + t;
       const int r = item >> 3, c8 = item & 7;
-      const int k = k0 + c8 * 8;
-      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (m0 + r < g.M && k < g.K) {
-        const float* s = x + pe_row_base(g, m0 + r) + pe_k_off(g, k);
-        const float4 a = *(const float4*)s, b = *(const float4*)(s + 4);      // p >= 8: 8 consecutive k' share an image row
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-      }
+      const float v[8] = {ra[u][0].x, ra[u][0].y, ra[u][0].z, ra[u][0].w, ra[u][1].x, ra[u][1].y, ra[u][1].z, ra[u][1].w};
       uint4 hi, lo;
       split8(v, hi, lo);
       *(uint4*)(sA + r * PW_APITCH + c8 * 16) = hi;
       *(uint4*)(sA + PE_M * PW_APITCH + r * PW_APITCH + c8 * 16) = lo;
     }
     // ---- g_out rows (frame-block row 1 + j)
-    for (int item = t; item < PE_M * NC; item += 256) {
-      const int r = item / NC, c = item - r * NC;
-      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      const int m = m0 + r;
-      if (m < g.M) {
-        const int bt = m / g.n, j = m - bt * g.n;
-        const float* s = gout + ((size_t)bt * (g.n + 1) + 1 + j) * g.dim + c * 8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) if (c * 8 + e < g.dim) v[e] = s[e];
+    for (int u = 0; u < NYI; ++u) {
+      const int item = u * 256 + t;
+      if (item < PE_M * NC) {
+        const int r = item / NC, c = item - r * NC;
+        const float v[8] = {ry[u][0].x, ry[u][0].y, ry[u][0].z, ry[u][0].w, ry[u][1].x, ry[u][1].y, ry[u][1].z, ry[u][1].w};
+        uint4 hi, lo;
+        split8(v, hi, lo);
+        *(uint4*)(sY + r * ypitch + c * 16) = hi;
+        *(uint4*)(sY + ylo + r * ypitch + c * 16) = lo;
       }
-      uint4 hi, lo;
-      split8(v, hi, lo);
-      *(uint4*)(sY + r * ypitch + c * 16) = hi;
-      *(uint4*)(sY + ylo + r * ypitch + c * 16) = lo;
     }
     __syncthreads();
+    if (box + 1 < box_end) load_box(box + 1);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int r0 = s * 32 + lg * 4 + lq;

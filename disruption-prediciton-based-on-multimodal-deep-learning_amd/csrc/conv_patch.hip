@@ -629,6 +629,15 @@ const PatchPlan* patch_lookup(const MdConvDesc* d, int dgrad) {
     static const int dis_d = getenv("MD_PATCH_DGRAD") && atoi(getenv("MD_PATCH_DGRAD")) == 0;
     if ((dgrad && dis_d) || (!dgrad && dis_f)) return nullptr;
   }
+  {   // A Linear over rows (1x1x1, unit stride, the rows laid along W of a single image: models/_unit.py::LinearRowsFunction) with
+      // many rows goes to the K-streaming GEMM (k_linear_split: three stages in flight, no per-box tables) instead of the per-box kernel
+      // (whose two-stage K loop at K = 128 is all prologue: 15 of 43 us are box tables and the first weight stage's latency,
+      // tools/r03_linear_abl.py).  ViViT cfg3 captured step 2.489 -> 2.426 ms; MD_LINEAR_PREFER=0 restores the per-box kernel.
+    static const int prefer = getenv("MD_LINEAR_PREFER") ? atoi(getenv("MD_LINEAR_PREFER")) : 1;
+    if (prefer && d->kt == 1 && d->kh == 1 && d->kw == 1 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 && d->ph == 0 && d->pw == 0 &&
+        d->N == 1 && d->Ti == 1 && d->Hi == 1 && d->Wi >= 4096 && (d->Cin & 3) == 0 && (d->Cout & 3) == 0)
+      return nullptr;
+  }
   static std::mutex mu;
   static std::map<std::array<int, 20>, PatchPlan*> cache;    // value nullptr = does not qualify
   std::array<int, 20> key = {d->N, d->Ti, d->Hi, d->Wi, d->Cin, d->To, d->Ho, d->Wo, d->Cout, d->kt, d->kh, d->kw,

@@ -131,10 +131,10 @@ __global__ __launch_bounds__(256) void k_lstm_wgrad(const float* __restrict__ dp
 // one quarter of the rows (dh_k = sum_j W_hh[j][k] dpre_j as four partial sums added in a fixed order).  Per step only h / dpre
 // travel through LDS as broadcast ds_read_b128.
 template <int H>
-__global__ __launch_bounds__(4 * H) void k_lstm_rec_fwd(const float* __restrict__ xproj, const float* __restrict__ w_hh,
-                                                       const float* __restrict__ b_ih, const float* __restrict__ b_hh, int S, int B,
-                                                       int reverse, float* __restrict__ h_all, float* __restrict__ c_all,
-                                                       float* __restrict__ gates) {
+__device__ __forceinline__ void lstm_rec_fwd_body(const float* __restrict__ xproj, const float* __restrict__ w_hh,
+                                                  const float* __restrict__ b_ih, const float* __restrict__ b_hh, int S, int B,
+                                                  int reverse, float* __restrict__ h_all, float* __restrict__ c_all,
+                                                  float* __restrict__ gates) {
   __shared__ __attribute__((aligned(16))) float hprev[H];
   __shared__ float cprev[H];
   __shared__ float pre[4 * H];
@@ -172,9 +172,25 @@ __global__ __launch_bounds__(4 * H) void k_lstm_rec_fwd(const float* __restrict_
   }
 }
 template <int H>
-__global__ __launch_bounds__(4 * H) void k_lstm_rec_bwd(const float* __restrict__ dh_all, const float* __restrict__ w_hh,
-                                                       const float* __restrict__ c_all, const float* __restrict__ gates, int S, int B,
-                                                       int reverse, float* __restrict__ dpre) {
+__global__ __launch_bounds__(4 * H) void k_lstm_rec_fwd(const float* __restrict__ xproj, const float* __restrict__ w_hh,
+                                                       const float* __restrict__ b_ih, const float* __restrict__ b_hh, int S, int B,
+                                                       int reverse, float* __restrict__ h_all, float* __restrict__ c_all,
+                                                       float* __restrict__ gates) {
+  lstm_rec_fwd_body<H>(xproj, w_hh, b_ih, b_hh, S, B, reverse, h_all, c_all, gates);
+}
+// Both directions of a bidirectional layer in ONE launch (blockIdx.y = direction): the two recurrences are independent chains of S
+// dependent steps (2 us each), and one after the other they were 8 x 45 us on cfg5's critical path for a model that occupies 8 CUs.
+struct LstmRec2 { const float* xproj[2]; const float* w_hh[2]; const float* b_ih[2]; const float* b_hh[2]; float* h_all[2]; float* c_all[2];
+                  float* gates[2]; };
+template <int H>
+__global__ __launch_bounds__(4 * H) void k_lstm_rec_fwd2(LstmRec2 a, int S, int B) {
+  const int d = blockIdx.y;
+  lstm_rec_fwd_body<H>(a.xproj[d], a.w_hh[d], a.b_ih[d], a.b_hh[d], S, B, d, a.h_all[d], a.c_all[d], a.gates[d]);
+}
+template <int H>
+__device__ __forceinline__ void lstm_rec_bwd_body(const float* __restrict__ dh_all, const float* __restrict__ w_hh,
+                                                  const float* __restrict__ c_all, const float* __restrict__ gates, int S, int B,
+                                                  int reverse, float* __restrict__ dpre) {
   __shared__ float dh[H];
   __shared__ float dc[H];
   __shared__ __attribute__((aligned(16))) float dg[4 * H];
@@ -217,7 +233,81 @@ __global__ __launch_bounds__(4 * H) void k_lstm_rec_bwd(const float* __restrict_
     __syncthreads();
   }
 }
+template <int H>
+__global__ __launch_bounds__(4 * H) void k_lstm_rec_bwd(const float* __restrict__ dh_all, const float* __restrict__ w_hh,
+                                                       const float* __restrict__ c_all, const float* __restrict__ gates, int S, int B,
+                                                       int reverse, float* __restrict__ dpre) {
+  lstm_rec_bwd_body<H>(dh_all, w_hh, c_all, gates, S, B, reverse, dpre);
+}
+struct LstmRecBwd2 { const float* dh_all[2]; const float* w_hh[2]; const float* h_all[2]; const float* c_all[2]; const float* gates[2];
+                     float* dpre[2]; float* dw_hh[2]; float* db[2]; };
+template <int H>
+__global__ __launch_bounds__(4 * H) void k_lstm_rec_bwd2(LstmRecBwd2 a, int S, int B) {
+  const int d = blockIdx.y;
+  lstm_rec_bwd_body<H>(a.dh_all[d], a.w_hh[d], a.c_all[d], a.gates[d], S, B, d, a.dpre[d]);
+}
+// dW_hh / db of both directions (k_lstm_wgrad with I = 0), blockIdx.y = direction
+__global__ __launch_bounds__(256) void k_lstm_wgrad2(LstmRecBwd2 a, int S, int B, int H) {
+  const int d = blockIdx.y;
+  const float* __restrict__ dpre = a.dpre[d]; const float* __restrict__ h_all = a.h_all[d];
+  const int total = 4 * H * (H + 1);
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int j = e / (H + 1), c = e - j * (H + 1);
+    float acc = 0.f;
+    for (int ts = 0; ts < S; ++ts) {
+      const int tprev = d ? ts + 1 : ts - 1;
+      const bool has_prev = d ? ts + 1 < S : ts > 0;
+      for (int b = 0; b < B; ++b) {
+        const float g = dpre[((size_t)ts * B + b) * 4 * H + j];
+        const float v = c < H ? (has_prev ? h_all[((size_t)tprev * B + b) * H + c] : 0.f) : 1.f;
+        acc = fmaf(g, v, acc);
+      }
+    }
+    if (c < H) a.dw_hh[d][(size_t)j * H + c] = acc; else a.db[d][j] = acc;
+  }
+}
 extern "C" int md_lstm_rec_supported(int32_t H) { return (H == 64 || H == 128) ? 1 : 0; }
+// Both directions of one bidirectional layer: index 0 = forward in time, 1 = reverse; arrays of two device pointers each.
+extern "C" int md_lstm_rec_fwd2(const float* const* xproj, const float* const* w_hh, const float* const* b_ih, const float* const* b_hh,
+                                int32_t S, int32_t B, int32_t H, float* const* h_all, float* const* c_all, float* const* gates, void* stream) {
+  if (!xproj || !w_hh || !b_ih || !b_hh || !h_all || !c_all || !gates) return MD_ERR_NULL;
+  LstmRec2 a;
+  for (int d = 0; d < 2; ++d) {
+    if (!xproj[d] || !w_hh[d] || !b_ih[d] || !b_hh[d] || !h_all[d] || !c_all[d] || !gates[d]) return MD_ERR_NULL;
+    a.xproj[d] = xproj[d]; a.w_hh[d] = w_hh[d]; a.b_ih[d] = b_ih[d]; a.b_hh[d] = b_hh[d]; a.h_all[d] = h_all[d]; a.c_all[d] = c_all[d];
+    a.gates[d] = gates[d];
+  }
+  if (S <= 0 || B <= 0) return MD_ERR_BAD_SHAPE;
+  if (!md_lstm_rec_supported(H)) return MD_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (H == 64) MD_KLAUNCH(k_lstm_rec_fwd2<64>, dim3(B, 2), dim3(256), 0, s, a, S, B);
+  else MD_KLAUNCH(k_lstm_rec_fwd2<128>, dim3(B, 2), dim3(512), 0, s, a, S, B);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
+// dw_hh / db: both NULL arrays = the caller reduces dpre itself (as md_lstm_rec_bwd)
+extern "C" int md_lstm_rec_bwd2(const float* const* dh_all, const float* const* w_hh, const float* const* h_all, const float* const* c_all,
+                                const float* const* gates, int32_t S, int32_t B, int32_t H, float* const* dpre, float* const* dw_hh,
+                                float* const* db, void* stream) {
+  if (!dh_all || !w_hh || !h_all || !c_all || !gates || !dpre || (!dw_hh != !db)) return MD_ERR_NULL;
+  LstmRecBwd2 a;
+  for (int d = 0; d < 2; ++d) {
+    if (!dh_all[d] || !w_hh[d] || !h_all[d] || !c_all[d] || !gates[d] || !dpre[d]) return MD_ERR_NULL;
+    if (dw_hh && (!dw_hh[d] || !db[d])) return MD_ERR_NULL;
+    a.dh_all[d] = dh_all[d]; a.w_hh[d] = w_hh[d]; a.h_all[d] = h_all[d]; a.c_all[d] = c_all[d]; a.gates[d] = gates[d]; a.dpre[d] = dpre[d];
+    a.dw_hh[d] = dw_hh ? dw_hh[d] : nullptr; a.db[d] = db ? db[d] : nullptr;
+  }
+  if (S <= 0 || B <= 0) return MD_ERR_BAD_SHAPE;
+  if (!md_lstm_rec_supported(H)) return MD_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (H == 64) MD_KLAUNCH(k_lstm_rec_bwd2<64>, dim3(B, 2), dim3(256), 0, s, a, S, B);
+  else MD_KLAUNCH(k_lstm_rec_bwd2<128>, dim3(B, 2), dim3(512), 0, s, a, S, B);
+  MD_CHECK_LAUNCH();
+  if (!dw_hh) return MD_OK;
+  MD_KLAUNCH(k_lstm_wgrad2, dim3(md_cdiv(4 * H * (H + 1), 256), 2), dim3(256), 0, s, a, S, B, H);
+  MD_CHECK_LAUNCH();
+  return MD_OK;
+}
 // xproj [S][B][4H] = x W_ih^T (no bias); the biases are added here.
 extern "C" int md_lstm_rec_fwd(const float* xproj, const float* w_hh, const float* b_ih, const float* b_hh, int32_t S, int32_t B, int32_t H,
                                int32_t reverse, float* h_all, float* c_all, float* gates, void* stream) {

@@ -150,6 +150,8 @@ SIGNATURES = {
     "md_lstm_rec_supported": (C.c_int, [_I32]),
     "md_lstm_rec_fwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P]),
     "md_lstm_rec_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P]),
+    "md_lstm_rec_fwd2": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P, _P]),
+    "md_lstm_rec_bwd2": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P, _P]),
     "md_clip_preprocess": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, C.POINTER(C.c_float), _I32, _P, _P]),
     "md_clip_augment_preprocess": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, C.POINTER(C.c_float), _I32, _P, _P, _P, _P]),
     "md_multinomial_shard_count": (C.c_int64, [C.c_int64, _I32, _I32]),

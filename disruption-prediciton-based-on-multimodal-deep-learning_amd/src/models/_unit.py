@@ -436,6 +436,59 @@ class LSTMRecurrentFunction(torch.autograd.Function):
         return dpre, dw_hh, db, db.clone(), None
 
 
+import os as _os
+_LSTM_BI = _os.environ.get("MD_LSTM_BI", "1") != "0"       # A/B switch: one launch per direction again
+
+
+class LSTMBiRecurrentFunction(torch.autograd.Function):
+    """Both directions of one bidirectional LSTM layer on their precomputed input projections, one launch each way
+    (md_lstm_rec_fwd2 / md_lstm_rec_bwd2): (xproj_f, xproj_r) (S,B,4H) each -> (h_f, h_r).  Same arithmetic per direction as
+    LSTMRecurrentFunction -- the two recurrences only stop waiting for each other."""
+
+    @staticmethod
+    def forward(ctx, xf, xr, whf, whr, bif, bhf, bir, bhr):
+        xf = ops.f32(xf).contiguous(); xr = ops.f32(xr).contiguous()
+        ops.require_cuda(xf, xr, whf, whr, bif, bhf, bir, bhr)
+        S, B, H4 = xf.shape
+        H = H4 // 4
+        dev = xf.device
+        h = [torch.empty((S, B, H), device=dev) for _ in range(2)]
+        c = [torch.empty((S, B, H), device=dev) for _ in range(2)]
+        gates = [torch.empty_like(xf), torch.empty_like(xr)]
+        wh = [whf.contiguous(), whr.contiguous()]
+        P = lambda ts: (C.c_void_p * 2)(*[t.data_ptr() for t in ts])      # noqa: E731
+        N.check(N.lib().md_lstm_rec_fwd2(P([xf, xr]), P(wh), P([bif.contiguous(), bir.contiguous()]), P([bhf.contiguous(), bhr.contiguous()]),
+                                         S, B, H, P(h), P(c), P(gates), ops._stream()), "md_lstm_rec_fwd2")
+        ctx.save_for_backward(wh[0], wh[1], h[0], h[1], c[0], c[1], gates[0], gates[1])
+        return h[0], h[1]
+
+    @staticmethod
+    def backward(ctx, dhf, dhr):
+        whf, whr, hf, hr, cf, cr, gf, gr = ctx.saved_tensors
+        S, B, H = hf.shape
+        dev = hf.device
+        rows = S * B
+        dh = [ops.f32(dhf if dhf is not None else torch.zeros_like(hf)).contiguous(), ops.f32(dhr if dhr is not None else torch.zeros_like(hr)).contiguous()]
+        dpre = [torch.empty_like(gf), torch.empty_like(gr)]
+        gemm = rows >= 512 and not N.lib().md_get_exact_fp32()
+        dw = None if gemm else [torch.empty((4 * H, H), device=dev) for _ in range(2)]
+        db = [torch.empty(4 * H, device=dev) for _ in range(2)]
+        P = lambda ts: (C.c_void_p * 2)(*[t.data_ptr() for t in ts])      # noqa: E731
+        N.check(N.lib().md_lstm_rec_bwd2(P(dh), P([whf, whr]), P([hf, hr]), P([cf, cr]), P([gf, gr]), S, B, H, P(dpre),
+                                         None if gemm else P(dw), None if gemm else P(db), ops._stream()), "md_lstm_rec_bwd2")
+        if gemm:        # many (t, b) rows: the MFMA weight gradient + column sums, per direction (see LSTMRecurrentFunction.backward)
+            dw = []
+            for d_, (h_, dp_) in enumerate(((hf, dpre[0]), (hr, dpre[1]))):
+                zero = h_.new_zeros(1, B, H)
+                hprev = torch.cat((h_[1:], zero)) if d_ else torch.cat((zero, h_[:-1]))
+                dd = ops.make_desc(1, 1, 1, rows, H, 4 * H, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+                dw.append(ops.conv_wgrad(dd, ops.view(hprev.view(rows, H)), dp_.view(rows, 4 * H)).view(4 * H, H))
+                ns = N.lib().md_channel_bias_bwd_scratch_floats(rows, 4 * H, 1)
+                scratch = torch.empty(ns, device=dev) if ns else None
+                N.check(N.lib().md_channel_bias_bwd(ops._p(dp_), rows, 4 * H, 1, ops._p(db[d_]), ops._p(scratch), ops._stream()), "md_channel_bias_bwd")
+        return dpre[0], dpre[1], dw[0], dw[1], db[0], db[0].clone(), db[1], db[1].clone()
+
+
 def lstm_direction(x, w_ih, w_hh, b_ih, b_hh, reverse):
     """One direction of one layer: register-resident recurrence behind an MFMA input projection where the width allows,
     else the general kernels."""
@@ -461,10 +514,17 @@ def lstm_forward(x, lstm: torch.nn.LSTM):
             mask = torch.empty_like(out).bernoulli_(keep)
             out = _MaskScale.apply(out, mask, 1.0 / keep)
         dirs = []
-        for rev in range(2 if lstm.bidirectional else 1):
-            sfx = f"_l{layer}" + ("_reverse" if rev else "")
-            dirs.append(lstm_direction(out, getattr(lstm, "weight_ih" + sfx), getattr(lstm, "weight_hh" + sfx),
-                                       getattr(lstm, "bias_ih" + sfx), getattr(lstm, "bias_hh" + sfx), rev))
+        if lstm.bidirectional and out.is_cuda and N.lib().md_lstm_rec_supported(int(lstm.hidden_size)) and _LSTM_BI:
+            # both directions' recurrences in one launch each way (the input projections stay one MFMA GEMM per direction)
+            S, B, I = out.shape
+            par = [[getattr(lstm, n + f"_l{layer}" + sfx) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")] for sfx in ("", "_reverse")]
+            xp = [LinearRowsFunction.apply(out.reshape(S * B, I), p[0]).reshape(S, B, 4 * lstm.hidden_size) for p in par]
+            dirs = list(LSTMBiRecurrentFunction.apply(xp[0], xp[1], par[0][1], par[1][1], par[0][2], par[0][3], par[1][2], par[1][3]))
+        else:
+            for rev in range(2 if lstm.bidirectional else 1):
+                sfx = f"_l{layer}" + ("_reverse" if rev else "")
+                dirs.append(lstm_direction(out, getattr(lstm, "weight_ih" + sfx), getattr(lstm, "weight_hh" + sfx),
+                                           getattr(lstm, "bias_ih" + sfx), getattr(lstm, "bias_hh" + sfx), rev))
         out = dirs[0] if len(dirs) == 1 else torch.cat(dirs, dim=2)
     return out
 

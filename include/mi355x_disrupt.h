@@ -413,6 +413,13 @@ int md_lstm_rec_fwd(const float* xproj, const float* w_hh, const float* b_ih, co
                     int32_t reverse, float* h_all, float* c_all, float* gates, void* stream);
 int md_lstm_rec_bwd(const float* dh_all, const float* w_hh, const float* h_all, const float* c_all, const float* gates, int32_t S,
                     int32_t B, int32_t H, int32_t reverse, float* dpre, float* dw_hh, float* db, void* stream);
+/* Both directions of one bidirectional layer in one launch each way (arrays of two device pointers: [0] forward in time, [1] reverse):
+ * the two recurrences are independent chains of S dependent steps, run side by side instead of one after the other. */
+int md_lstm_rec_fwd2(const float* const* xproj, const float* const* w_hh, const float* const* b_ih, const float* const* b_hh,
+                     int32_t S, int32_t B, int32_t H, float* const* h_all, float* const* c_all, float* const* gates, void* stream);
+int md_lstm_rec_bwd2(const float* const* dh_all, const float* const* w_hh, const float* const* h_all, const float* const* c_all,
+                     const float* const* gates, int32_t S, int32_t B, int32_t H, float* const* dpre, float* const* dw_hh,
+                     float* const* db, void* stream);
 int md_lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, int32_t S,
                 int32_t B, int32_t I, int32_t H, int32_t reverse, float* h_all, float* c_all, float* gates, void* stream);
 int md_lstm_bwd(const float* dh_all, const float* x, const float* w_ih, const float* w_hh, const float* h_all,

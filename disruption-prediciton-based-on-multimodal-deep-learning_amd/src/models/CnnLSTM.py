@@ -73,7 +73,7 @@ class CnnLSTM(nn.Module):
         c1, c2, bn = self.conv[0], self.conv[1], self.conv[2]
         x5 = x_bft.contiguous()[:, :, :, None, None]
         y = ConvFunction.apply(x5, c1.weight[:, :, :, None, None], (c1.stride[0], 1, 1), (c1.padding[0], 0, 0))
-        y = _ChannelBias.apply(y[:, :, :, 0, 0], c1.bias)
+        y = _ChannelBias.apply(y.squeeze(4).squeeze(3), c1.bias)
         b = c2.bias.detach()
         rmean = bn.running_mean if self.training else bn.running_mean - b
         z = ConvBnLeakyFunction.apply(y[:, :, :, None, None], c2.weight[:, :, :, None, None], bn.weight, bn.bias, rmean,
@@ -83,7 +83,7 @@ class CnnLSTM(nn.Module):
             bn.running_mean.add_(b * bn.momentum)
             bump_batches_tracked(bn)
             z = _AbsorbedBias.apply(z, c2.bias)
-        return z[:, :, :, 0, 0]
+        return z.squeeze(4).squeeze(3)
 
     def _hidden(self, x):
         x = self.noise(x)

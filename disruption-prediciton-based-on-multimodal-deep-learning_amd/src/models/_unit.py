@@ -678,7 +678,7 @@ def conv1d_bn_leaky(x_bct, conv: torch.nn.Conv1d, bn: torch.nn.BatchNorm1d, slop
     reference) and gets its exact zero gradient."""
     z = _unit_with_bias(x_bct.contiguous()[:, :, :, None, None], conv.weight[:, :, :, None, None], conv.bias, bn,
                         (conv.stride[0], 1, 1), (conv.padding[0], 0, 0), slope, training)
-    return z[:, :, :, 0, 0]
+    return z.squeeze(4).squeeze(3)          # (views: a select here would cost zeros + copy in the backward)
 
 
 def linear_bn_leaky(x, lin: torch.nn.Linear, bn: torch.nn.BatchNorm1d, slope: float, training: bool):
@@ -715,7 +715,7 @@ def linear(x, lin: torch.nn.Linear):
     """nn.Linear on (B, D) rows as a 1x1x1 convolution plus the per-channel bias kernel."""
     y = ConvFunction.apply(x.contiguous()[:, :, None, None, None], lin.weight[:, :, None, None, None], (1, 1, 1), (0, 0, 0))
     y = y[:, :, 0, 0, 0]
-    return y if lin.bias is None else _ChannelBias.apply(y[:, :, None], lin.bias)[:, :, 0]
+    return y if lin.bias is None else _ChannelBias.apply(y[:, :, None], lin.bias).squeeze(2)
 
 
 def _ln_backward(g, gamma, xhat, rstd, dres):
@@ -851,7 +851,7 @@ def branch_residual_layernorm(y2d, bias, p: float, training: bool, res, norm):
     if res.is_cuda and N.lib().md_branch_layernorm_supported(rows, D) and (not drop or site is not None):
         s, h = BranchResidualLayerNormFunction.apply(y2d.reshape(res.shape), bias, res, norm.weight, norm.bias, norm.eps, site, 1.0 - p if drop else 1.0)
         return s, h
-    y = y2d if bias is None else _ChannelBias.apply(y2d.contiguous()[:, :, None], bias)[:, :, 0]
+    y = y2d if bias is None else _ChannelBias.apply(y2d.contiguous()[:, :, None], bias).squeeze(2)
     if drop:
         keep = 1.0 - p
         y = CtrDropoutFunction.apply(y, site[0], site[1], keep) if site is not None else \
@@ -1072,7 +1072,7 @@ def linear_bias_gelu_dropout(x2d, weight, bias, p: float, training: bool, kind: 
     multiple of 4 or the Linear has no bias)."""
     y = LinearRowsFunction.apply(x2d, weight)
     if bias is None or y.shape[1] % 4:
-        return dropout(GeluFunction.apply(y if bias is None else _ChannelBias.apply(y.contiguous()[:, :, None], bias)[:, :, 0], kind), p, training)
+        return dropout(GeluFunction.apply(y if bias is None else _ChannelBias.apply(y.contiguous()[:, :, None], bias).squeeze(2), kind), p, training)
     y = y.contiguous()
     if training and p > 0.0:
         keep = 1.0 - p
@@ -1086,7 +1086,7 @@ def linear_bias_gelu_dropout(x2d, weight, bias, p: float, training: bool, kind: 
 def linear_wb(x2d, weight, bias):
     """x (rows, D_in) @ weight(D_out, D_in)^T + bias: the rows-major 1x1x1 convolution plus the per-channel bias kernel."""
     y = LinearRowsFunction.apply(x2d, weight)
-    return y if bias is None else _ChannelBias.apply(y.contiguous()[:, :, None], bias)[:, :, 0]
+    return y if bias is None else _ChannelBias.apply(y.contiguous()[:, :, None], bias).squeeze(2)
 
 
 def dropout(x, p: float, training: bool):

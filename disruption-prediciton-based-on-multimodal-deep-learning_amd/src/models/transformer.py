@@ -89,7 +89,7 @@ class TransformerEncoder(nn.Module):
         c1, c2, bn = self.filter[0], self.filter[1], self.filter[2]
         y = ConvFunction.apply(x_bft.contiguous()[:, :, :, None, None], c1.weight[:, :, :, None, None], (c1.stride[0], 1, 1),
                                (c1.padding[0], 0, 0))
-        y = _ChannelBias.apply(y[:, :, :, 0, 0], c1.bias)
+        y = _ChannelBias.apply(y.squeeze(4).squeeze(3), c1.bias)
         return conv1d_bn_leaky(y, c2, bn, 0.0, self.training)
 
     def forward(self, x: torch.Tensor):

@@ -660,8 +660,11 @@ const PatchPlan* patch_lookup(const MdConvDesc* d, int dgrad) {
     pers_try(d, dgrad, nullptr, g, &pp->pers);
     pp->half = false;
     // 64-pixel form: where the 128-pixel workgroup owns the CU's LDS (> 80 KB: nothing overlaps its staging) and the half-size
-    // one fits twice, or where the layer has too few boxes to fill the chip.  MD_PATCH_HALF: 0 never, 1 automatic, 2 whenever built.
-    static const int half_env = getenv("MD_PATCH_HALF") ? atoi(getenv("MD_PATCH_HALF")) : 1;
+    // one fits twice, or where the layer has too few boxes to fill the chip.  MD_PATCH_HALF: 0 never, 1 both rules, 2 whenever built,
+    // 3 / 4 one rule only.  Default 0 since the end of round 3: with the one-stream schedule and the second-form weight gradients
+    // neither rule pays any more (bench, interleaved on one box: 1 -> 1355 / 1361 clips/s, 3 -> 1360 / 1363, 4 -> 1369 / 1366,
+    // 0 -> 1372 / 1370; cfg5 656 / 658 -> 659 / 662); the variant stays built and tested (tests/test_patch_half_gpu.py).
+    static const int half_env = getenv("MD_PATCH_HALF") ? atoi(getenv("MD_PATCH_HALF")) : 0;
     const bool strided_dg = dgrad && (d->st != 1 || d->sh != 1 || d->sw != 1);
     if (half_env && !pp->pers.on && !strided_dg && g.N16 >= 32) {
       const size_t cap2 = 80 * 1024 - 256;
@@ -679,7 +682,9 @@ const PatchPlan* patch_lookup(const MdConvDesc* d, int dgrad) {
         // counts; the layers with a handful of boxes gain from the extra workgroups (128 -> 288 at 8x8: 19 -> 14 us).
         const bool two_per_cu = nch == 1 && lds > cap2 + 256 && ldsh <= cap2;
         const bool few_boxes = boxes_full < 64;
-        if (half_env == 2 || two_per_cu || few_boxes) { pp->half = true; pp->gh = gh; pp->ldsh = ldsh; pp->half_npb = npb; }
+        // MD_PATCH_HALF: 0 never, 1 both rules, 2 whenever built, 3 the few-boxes rule only, 4 the two-per-CU rule only
+        const bool take = half_env == 2 || (two_per_cu && (half_env == 1 || half_env == 4)) || (few_boxes && (half_env == 1 || half_env == 3));
+        if (take) { pp->half = true; pp->gh = gh; pp->ldsh = ldsh; pp->half_npb = npb; }
         break;
       }
     }

@@ -514,7 +514,8 @@ const Wgrad2Plan* wgrad2_lookup(const MdConvDesc* d, int beside, int xpitch, int
     // or two boxes, that traffic exceeds the operands' several times over (64 -> 144 at 16x16: 32 MB of slabs, 10 MB of operands).
     // There a workgroup takes at least `minb` boxes as long as `minw` workgroups remain: time-neutral (profiles/r03_wgrad2.txt),
     // 0.4 GB less HBM traffic per step.
-    static const int minb = getenv("MD_W2_MIN_BOXES") ? atoi(getenv("MD_W2_MIN_BOXES")) : 4;
+    // (end of round 3: 2 boxes instead of 4 -- together with MD_PATCH_HALF=0 the bench went 1358-1368 -> 1380-1384 clips/s, interleaved)
+    static const int minb = getenv("MD_W2_MIN_BOXES") ? atoi(getenv("MD_W2_MIN_BOXES")) : 2;
     static const int minw = getenv("MD_W2_MIN_WGS") ? atoi(getenv("MD_W2_MIN_WGS")) : 128;
     if (minb > 1 && g.nboxes / want < minb) {
       int w2 = g.nboxes / minb;

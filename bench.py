@@ -42,7 +42,7 @@ PEAK_16BIT_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16/fp16 MF
 PRODUCTS_PER_MULTIPLY = 3              # split arithmetic: hi*hi + hi*lo + lo*hi
 PEAK_SPLIT_TFLOPS = PEAK_16BIT_MFMA_TFLOPS / PRODUCTS_PER_MULTIPLY
 PEAK_HBM_GBS = 8000.0
-EVENT_EVERY = 10                        # timed steps between two steps whose conv launches are timed with HIP events
+EVENT_EVERY = 20                        # timed steps between two steps whose conv launches are timed with HIP events
 
 
 def synth_batch(device, seed):
@@ -213,19 +213,19 @@ def main():
     plan = model.res2plus1d._plans[(B_PER_GPU, T, S, S)]
     # Kernel durations for the roofline object come from HIP events stamped by the conv launches themselves (hipExtLaunchKernel's
     # start / stop events, csrc/common.h::md_klaunch).  A timed launch does not overlap its neighbours' dispatch, which costs a sampled
-    # step ~0.45 ms (6.23 vs 5.76 ms), so the timed region samples every EVENT_EVERY-th step (step 0, 10, ...): the events are live
-    # and inside the timed region, the perturbation < 1 %.
+    # step ~0.45 ms (6.23 vs 5.76 ms), so the timed region samples one step in EVENT_EVERY (step 10, 30, ...: 63 launches of the
+    # dominant family each): the events are live and inside the timed region, the perturbation ~0.4 %.
     plan.profile_enable(True); plan.profile_enable(False)        # forget anything recorded during warm-up
     if not args.no_kernel_events:
         # the event pairs of every sampled step exist before the clock starts (created on first use they cost the host 11-13 ms per
         # sampled step: 380 hipEventCreate calls, long enough for the GPU queue to run dry)
-        plan.profile_reserve(((args.steps + EVENT_EVERY - 1) // EVENT_EVERY) * 3 * plan.num_units + 64)
+        plan.profile_reserve((args.steps // EVENT_EVERY + 1) * 3 * plan.num_units + 64)
     sampled = [0]
 
     def events_for(i):
         if args.no_kernel_events:
             return
-        on = i % EVENT_EVERY == 0
+        on = i % EVENT_EVERY == min(EVENT_EVERY // 2, args.steps - 1)      # (a step in the middle of each window: 10, 30, ...)
         plan.profile_enable(on, keep=True)
         if on:
             sampled[0] += 1
@@ -313,7 +313,7 @@ def main():
                          "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": dom, "launches": int(d_n), "avg_launch_ms": round(d_ms / max(1, d_n), 5),
                          "alg_bytes_per_launch": round(alg_bytes_per_launch),
-                         "event_sampling": f"every {EVENT_EVERY}th timed step ({sampled[0]} of {args.steps})",
+                         "event_sampling": f"one timed step in {EVENT_EVERY} ({sampled[0]} of {args.steps})",
                          "whole_step_achieved": round(step_gbs, 1), "whole_step_frac": round(step_gbs / PEAK_HBM_GBS, 4),
                          "whole_step_note": "clips/s x 951.9e6 B (SURVEY 8(d), fp32 storage) against 8000 GB/s",
                          "mfma_view": {"achieved_tflops": round(mfma_tflops, 3), "peak_tflops": round(PEAK_SPLIT_TFLOPS, 1),

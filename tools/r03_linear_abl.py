@@ -4,7 +4,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'disruption-prediciton-based-on-multimodal-deep-learning_amd'))
 import torch
 from src import ops
-rows = 16548
+rows = int(os.environ.get("ROWS", "16548"))
 for name, din, dout in (("ff1 128->1024", 128, 1024), ("ff2 1024->128", 1024, 128), ("qkv 128->384", 128, 384), ("out 256->128", 256, 128)):
     d = ops.make_desc(1, 1, 1, rows, din, dout, (1, 1, 1), (1, 1, 1), (0, 0, 0))
     x = torch.randn(rows, din, device="cuda"); w = torch.randn(dout, din, device="cuda") * 0.05; dy = torch.randn(rows, dout, device="cuda")
